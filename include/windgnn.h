@@ -1,0 +1,136 @@
+/* windgnn.h — C ABI of libwindgnn_hip.so: the MI355X (gfx950) implementation of WindGNN's
+ * 2-layer GCN + GRU forward/backward hot path.
+ *
+ * The reference has no FFI of its own (it is pure Python on torch); what this library replaces is
+ * the body of the reference's operator API for the path, and each entry point cites the
+ * reference lines it stands in for (paths relative to the reference repo):
+ *
+ *   wgnn_fwd            GCN_GRU.forward            src/step6_gcn_gru_combined_model.py:13-27
+ *                       (GraphConvLayer.forward x2  src/step5_gcn_layer_model.py:13-23, nn.GRU :23)
+ *   wgnn_bwd            loss.backward() through it  src/main.py:79
+ *   wgnn_gcn_layer_fwd  GraphConvLayer.forward      src/step5_gcn_layer_model.py:13-23
+ *   wgnn_gcn_layer_bwd  its autograd backward       src/main.py:79
+ *   wgnn_mse_loss_grad  nn.MSELoss()(out, y) + dY   src/main.py:49,72
+ *   wgnn_adam_step      torch.optim.Adam.step()     src/main.py:52,80
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / C++ types.
+ *   - Every data pointer is DEVICE memory owned by the caller (workspace and stash included);
+ *     the library allocates nothing persistent, keeps no mutable global state, frees nothing.
+ *   - All tensors are contiguous fp32 in the reference's layouts:
+ *       A [S,S] row-major, X [B,T,S,F] (F fastest), Y [B,T,H], L [B,T,H],
+ *       conv*.weight [F,F] (in,out), conv*.bias [F], w_ih [3H, S*F], w_hh [3H,H], b_ih/b_hh [3H],
+ *       GRU gate row order r,z,n (torch nn.GRU).
+ *   - Calls are asynchronous and ordered on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream).  Re-entrant across streams and devices; safe from any host thread.
+ *   - Return value: 0 on success, negative wgnn_status otherwise; never throws, never aborts.
+ *     wgnn_strerror() maps a status to text.
+ */
+#ifndef WINDGNN_H
+#define WINDGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WGNN_VERSION 100 /* 0.1.0 */
+
+typedef enum wgnn_status {
+  WGNN_OK = 0,
+  WGNN_ERR_NULL = -1,        /* a required pointer is NULL */
+  WGNN_ERR_SHAPE = -2,       /* a dimension is <= 0 or outside what the kernels support */
+  WGNN_ERR_DTYPE = -3,       /* unsupported dtype / math mode */
+  WGNN_ERR_WORKSPACE = -4,   /* workspace or stash smaller than wgnn_*_bytes() says */
+  WGNN_ERR_UNSUPPORTED = -5, /* e.g. adjacency format not built yet */
+  WGNN_ERR_HIP = -6          /* a HIP runtime call or kernel launch failed */
+} wgnn_status;
+
+/* math mode of the contractions (I/O is always fp32) */
+typedef enum wgnn_math {
+  WGNN_MATH_F32 = 0,   /* fp32-input MFMA: bitwise an fp32 fmaf chain */
+  WGNN_MATH_F16X3 = 1  /* split-fp16 (hi+lo) MFMA, 3 products, fp32 accumulate: fp32-grade error */
+} wgnn_math;
+
+typedef enum wgnn_adj_format { WGNN_ADJ_DENSE = 0, WGNN_ADJ_CSR = 1 } wgnn_adj_format;
+
+typedef struct wgnn_dims {
+  int32_t B;          /* windows in this call */
+  int32_t T;          /* timesteps per window (seq_len) */
+  int32_t S;          /* stations (graph nodes) */
+  int32_t F;          /* features per node; the reference hard-codes 13 */
+  int32_t H;          /* GRU hidden width (reference: 3*S) */
+  int32_t math;       /* wgnn_math */
+  int32_t adj_format; /* wgnn_adj_format */
+  int32_t nnz;        /* CSR only */
+} wgnn_dims;
+
+/* The 8 tensors of the reference state_dict, in its key order. */
+typedef struct wgnn_params {
+  const float* conv1_weight; /* conv1.weight [F,F] */
+  const float* conv1_bias;   /* conv1.bias   [F]   */
+  const float* conv2_weight; /* conv2.weight [F,F] */
+  const float* conv2_bias;   /* conv2.bias   [F]   */
+  const float* w_ih;         /* gru.weight_ih_l0 [3H, S*F] */
+  const float* w_hh;         /* gru.weight_hh_l0 [3H, H]   */
+  const float* b_ih;         /* gru.bias_ih_l0   [3H]      */
+  const float* b_hh;         /* gru.bias_hh_l0   [3H]      */
+} wgnn_params;
+
+typedef struct wgnn_grads {
+  float* conv1_weight;
+  float* conv1_bias;
+  float* conv2_weight;
+  float* conv2_bias;
+  float* w_ih;
+  float* w_hh;
+  float* b_ih;
+  float* b_hh;
+} wgnn_grads;
+
+int wgnn_version(void);
+const char* wgnn_strerror(int status);
+
+/* Bytes of scratch wgnn_fwd / wgnn_bwd need (the larger of the two), and of the forward->backward
+ * stash.  Both depend on dims only. */
+size_t wgnn_workspace_bytes(const wgnn_dims* d);
+size_t wgnn_stash_bytes(const wgnn_dims* d);
+
+/* Y[B,T,H] = GRU(relu(A relu(A X W1 + b1) W2 + b2)), h0 = 0 per window.
+ * stash may be NULL (inference: src/main.py:100-102); otherwise it receives what wgnn_bwd needs. */
+int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, float* Y,
+             void* stash, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Gradients of sum(Y * dY) w.r.t. the 8 parameters (overwritten, not accumulated).
+ * No dX and no dA: neither requires grad in the reference (src/main.py:26,
+ * src/step4_sequence_preparer.py:58). */
+int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p,
+             const float* Y, const float* dY, const void* stash, const wgnn_grads* g,
+             void* workspace, size_t workspace_bytes, void* stream);
+
+/* One GraphConvLayer: out[n,S,F] = relu(A X[n] W + b) for n = 0..ntiles-1 (ntiles = prod of the
+ * leading dims of attr_matrix).  Backward: dW, db (overwritten) and, if dX != NULL, dX. */
+size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F);
+int wgnn_gcn_layer_fwd(int32_t ntiles, int32_t S, int32_t F, const float* A, const float* X,
+                       const float* W, const float* b, float* out, void* stream);
+int wgnn_gcn_layer_bwd(int32_t ntiles, int32_t S, int32_t F, const float* A, const float* X,
+                       const float* W, const float* out, const float* dout, float* dW, float* db,
+                       float* dX, void* workspace, size_t workspace_bytes, void* stream);
+
+/* loss[0] = mean((Y-L)^2) over n elements; dY = 2 (Y-L) * grad_scale / n.
+ * (grad_scale = 1/world_size under data parallel so that summed shard grads equal the
+ * big-batch gradient.)  workspace: >= 4096 bytes. */
+int wgnn_mse_loss_grad(const float* Y, const float* L, int64_t n, float grad_scale, float* dY,
+                       float* loss, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam defaults semantics on flat fp32 buffers of n elements; `step` is the 1-based
+ * step count AFTER this update (bias correction uses it). */
+int wgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   int32_t step, float lr, float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WINDGNN_H */

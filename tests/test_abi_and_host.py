@@ -1,0 +1,70 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/windgnn.h declares,
+argument validation works without touching a GPU, and the module mirrors the reference's API."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import PARAM_KEYS, ROOT, load_fixture
+
+
+def _lib():
+    from windgnn_amd import _lib as L
+    from windgnn_amd import build
+    build.build(verbose=False)
+    return L, L.load()
+
+
+def test_every_declared_symbol_is_exported():
+    L, lib = _lib()
+    hdr = open(os.path.join(ROOT, "include", "windgnn.h")).read()
+    declared = set(re.findall(r"\b(wgnn_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.EXPORTS), (declared ^ set(L.EXPORTS))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.wgnn_version() == 100
+
+
+def test_dims_validation_no_gpu_needed():
+    L, lib = _lib()
+    ok = L.Dims(4, 24, 34, 13, 102, 0, 0, 0)
+    assert lib.wgnn_workspace_bytes(ctypes.byref(ok)) > 0
+    assert lib.wgnn_stash_bytes(ctypes.byref(ok)) > 0
+    for bad in (L.Dims(0, 24, 34, 13, 102, 0, 0, 0), L.Dims(4, 24, 34, 12, 102, 0, 0, 0),
+                L.Dims(4, 24, 4096, 13, 12288, 0, 1, 10)):
+        assert lib.wgnn_workspace_bytes(ctypes.byref(bad)) == 0
+    p = L.Params()
+    rc = lib.wgnn_fwd(ctypes.byref(ok), None, None, ctypes.byref(p), None, None, None, 0, None)
+    assert rc == -1 and b"NULL" in lib.wgnn_strerror(rc)
+    bad = L.Dims(4, 24, 34, 12, 102, 0, 0, 0)
+    assert lib.wgnn_fwd(ctypes.byref(bad), None, None, ctypes.byref(p), None, None, None, 0, None) == -2
+
+
+def test_module_mirrors_reference_state_dict():
+    from windgnn_amd import GCN_GRU
+    m = GCN_GRU(input_dim=13, hidden_dim=13, output_dim=13, gru_input=34 * 13, gru_hidden_dim=102)
+    sd = m.state_dict()
+    assert list(sd.keys()) == PARAM_KEYS
+    fx = load_fixture("f3_s34_t24_b4_ckpt")          # parameters of the shipped wind_gnn_34.pth
+    m.load_state_dict(fx["params"])
+    assert sum(p.numel() for p in m.parameters()) == 167440
+    for k in PARAM_KEYS:
+        assert sd[k].shape == fx["params"][k].shape
+
+
+def test_no_cpu_fallback():
+    from windgnn_amd import GCN_GRU
+    m = GCN_GRU(13, 13, 13, 7 * 13, 21)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(7, 7), torch.rand(1, 12, 7, 13))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "windgnn_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,151 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures and the CPU oracle.
+Tolerances: Y <= 1e-4 max-abs; gradients <= 1e-4 relative to the tensor's max."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import PARAM_KEYS, load_fixture, max_abs, rel_to_max
+
+pytestmark = pytest.mark.gpu
+
+Y_TOL = 1e-4
+G_TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _model_from(params, S, H, math="f32"):
+    from windgnn_amd import GCN_GRU
+    m = GCN_GRU(13, 13, 13, S * 13, H, math=math)
+    m.load_state_dict({k: v.clone() for k, v in params.items()})   # reference keys, src/main.py:99
+    return m.to(_dev())
+
+
+def _run_step(model, A, X, L):
+    """src/main.py:66-79 with the library's MSE op."""
+    from windgnn_amd.functional import mse_loss_grad
+    model.zero_grad()
+    out = model(A, X)
+    Y = out if out.dim() == 3 else out.unsqueeze(0)
+    loss, dY = mse_loss_grad(Y, L)
+    Y.backward(dY)
+    grads = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    return out.detach().cpu(), float(loss), grads
+
+
+@pytest.mark.parametrize("math", ["f32"])
+def test_golden_forward_backward(golden, math):
+    dev = _dev()
+    S = golden["A"].shape[0]
+    H = golden["Y"].shape[-1]
+    model = _model_from(golden["params"], S, H, math)
+    assert list(model.state_dict().keys()) == PARAM_KEYS
+    A = torch.from_numpy(golden["A"]).to(dev)
+    X = torch.from_numpy(golden["X"]).to(dev)
+    L = torch.from_numpy(golden["L"]).to(dev)
+    out, loss, grads = _run_step(model, A, X, L)
+    B = X.shape[0]
+    assert tuple(out.shape) == ((X.shape[1], H) if B == 1 else (B, X.shape[1], H))   # squeeze(0), step6:26
+    assert max_abs(out.reshape(golden["Y"].shape), golden["Y"]) <= Y_TOL
+    assert abs(loss - float(golden["loss"])) <= 1e-5
+    for k in PARAM_KEYS:
+        assert rel_to_max(grads[k], golden["grads"][k]) <= G_TOL, k
+
+
+def test_inference_no_grad_matches(golden):
+    dev = _dev()
+    S, H = golden["A"].shape[0], golden["Y"].shape[-1]
+    model = _model_from(golden["params"], S, H)
+    with torch.no_grad():                                            # src/main.py:100-102
+        out = model(torch.from_numpy(golden["A"]).to(dev), torch.from_numpy(golden["X"]).to(dev))
+    assert max_abs(out.cpu().reshape(golden["Y"].shape), golden["Y"]) <= Y_TOL
+
+
+@pytest.mark.parametrize("S,T,B,H", [(34, 24, 256, 102), (7, 12, 32, 21), (34, 24, 37, 102), (5, 3, 17, 9),
+                                     (16, 4, 16, 48), (48, 2, 3, 33), (1, 1, 1, 1)])
+def test_against_oracle_random(S, T, B, H):
+    """BASELINE configs[1] (S=34,T=24,B=256 fp32), configs[0] shape, and ragged / edge shapes."""
+    from oracle import windgnn_oracle as orc
+    dev = _dev()
+    g = torch.Generator().manual_seed(1000 + S * 7 + B)
+    A = torch.rand(S, S, generator=g) / S + 0.01
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    p = orc.init_params(S, 13, H, seed=S + H)
+    Yo, loss_o, go = orc.train_step(A.double(), X.double(), L.double(), {k: v.double() for k, v in p.items()})
+    model = _model_from(p, S, H)
+    out, loss, grads = _run_step(model, A.to(dev), X.to(dev), L.to(dev))
+    assert max_abs(out.reshape(Yo.shape), Yo) <= Y_TOL
+    assert abs(loss - float(loss_o)) <= 1e-5 * max(1.0, float(loss_o))
+    for k in PARAM_KEYS:
+        assert rel_to_max(grads[k], go[k]) <= G_TOL, k
+
+
+def test_graph_conv_layer_module_with_input_grad():
+    """GraphConvLayer alone (src/step5_gcn_layer_model.py), including dX for a stacked use."""
+    from windgnn_amd import GraphConvLayer
+    dev = _dev()
+    torch.manual_seed(5)
+    S = 34
+    A = (torch.rand(S, S) / S + 0.01)
+    X = torch.rand(1, 6, S, 13, requires_grad=True)
+    layer = GraphConvLayer(13, 13)
+    ref_out = torch.relu(torch.matmul(torch.matmul(A.double(), X.double()), layer.weight.double()) + layer.bias.double())
+    dout = torch.rand_like(ref_out)
+    gX, gW, gb = torch.autograd.grad(ref_out, [X, layer.weight, layer.bias], dout)
+    layer_d = GraphConvLayer(13, 13).to(dev)
+    layer_d.load_state_dict(layer.state_dict())
+    Xd = X.detach().to(dev).requires_grad_(True)
+    out = layer_d(A.to(dev), Xd)
+    out.backward(dout.float().to(dev))
+    assert max_abs(out.detach().cpu(), ref_out) <= 1e-5
+    assert rel_to_max(Xd.grad.cpu(), gX) <= 1e-5
+    assert rel_to_max(layer_d.weight.grad.cpu(), gW) <= 1e-5
+    assert rel_to_max(layer_d.bias.grad.cpu(), gb) <= 1e-5
+
+
+def test_adam_three_steps_match_reference():
+    """src/main.py:52,80 on the flat-buffer Adam kernel, against the reference's parameters after
+    1 and 3 optimiser steps on a fixed batch."""
+    from windgnn_amd.functional import adam_step_
+    dev = _dev()
+    fx = load_fixture("f2b_s7_t12_b4_rand")
+    S, H = 7, 21
+    model = _model_from(fx["params"], S, H)
+    A, X, L = (torch.from_numpy(fx[k]).to(dev) for k in ("A", "X", "L"))
+    ps = list(model.parameters())
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    for step in (1, 2, 3):
+        _run_step(model, A, X, L)
+        with torch.no_grad():
+            for p, m, v in zip(ps, ms, vs):
+                adam_step_(p.data, p.grad, m, v, step)
+        if step in (1, 3):
+            for k, p in model.named_parameters():
+                assert max_abs(p.detach().cpu(), fx["a%d.%s" % (step, k)]) <= 2e-5, (step, k)
+
+
+def test_bitwise_run_to_run_determinism():
+    dev = _dev()
+    fx = load_fixture("f3b_s34_t24_b4_rand")
+    model = _model_from(fx["params"], 34, 102)
+    A, X, L = (torch.from_numpy(fx[k]).to(dev) for k in ("A", "X", "L"))
+    o1, l1, g1 = _run_step(model, A, X, L)
+    o2, l2, g2 = _run_step(model, A, X, L)
+    assert torch.equal(o1, o2) and l1 == l2
+    for k in PARAM_KEYS:
+        assert torch.equal(g1[k], g2[k]), k
+
+
+def test_errors_are_loud():
+    from windgnn_amd import GCN_GRU
+    dev = _dev()
+    m = GCN_GRU(13, 13, 13, 34 * 13, 102).to(dev)
+    with pytest.raises(RuntimeError):                      # CPU tensors: no fallback
+        m(torch.rand(34, 34), torch.rand(1, 4, 34, 13))
+    with pytest.raises(RuntimeError):                      # wrong station count (reference: .view fails)
+        m(torch.rand(7, 7, device=dev), torch.rand(1, 4, 7, 13, device=dev))

@@ -1,0 +1,80 @@
+"""ctypes binding of libwindgnn_hip.so (the C ABI declared in include/windgnn.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the shared object is
+missing or a call fails this module raises, loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwindgnn_hip.so")
+
+MATH_F32 = 0
+MATH_F16X3 = 1
+ADJ_DENSE = 0
+ADJ_CSR = 1
+
+
+class Dims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("S", C.c_int32), ("F", C.c_int32), ("H", C.c_int32),
+                ("math", C.c_int32), ("adj_format", C.c_int32), ("nnz", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("conv1_weight", "conv1_bias", "conv2_weight", "conv2_bias",
+                                          "w_ih", "w_hh", "b_ih", "b_hh")]
+
+
+class Grads(C.Structure):
+    _fields_ = Params._fields_
+
+
+EXPORTS = {
+    "wgnn_version": (C.c_int, []),
+    "wgnn_strerror": (C.c_char_p, [C.c_int]),
+    "wgnn_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
+    "wgnn_stash_bytes": (C.c_size_t, [C.POINTER(Dims)]),
+    "wgnn_fwd": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wgnn_bwd": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.POINTER(Grads), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wgnn_gcn_layer_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "wgnn_gcn_layer_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wgnn_gcn_layer_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
+    "wgnn_mse_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wgnn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise.  Never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "windgnn_amd: %s is missing. Build it with `python -m windgnn_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.wgnn_version() < 100:
+        raise RuntimeError("windgnn_amd: libwindgnn_hip.so is too old")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().wgnn_strerror(status).decode()
+        raise RuntimeError("windgnn_amd: %s failed: %s (status %d)" % (what, msg, status))

@@ -1,0 +1,223 @@
+// extern "C" entry points of libwindgnn_hip.so (declared in include/windgnn.h).
+// Orchestrates the kernels of gcn.hip / gemm.hip / gru.hip / train_ops.hip on the caller's stream,
+// inside caller-owned workspace and stash buffers.  No allocation, no host synchronisation.
+#include "common.h"
+
+namespace {
+
+struct Layout {
+  size_t BT, I, G3, H;
+  // forward workspace
+  size_t ws_GI, ws_g, fwd_floats;
+  // stash
+  size_t st_g, st_gates, stash_floats;
+  // backward workspace
+  size_t ws_dGI, ws_dGH, ws_dg, ws_part, ws_gcnpart, bwd_floats;
+  int sk_ih, sk_hh;
+};
+
+int pick_splitk(size_t BT, int tiles) {
+  // aim for ~1024 workgroups, at least 256 reduction rows each
+  int by_rows = (int)(BT / 256);
+  int by_grid = 1024 / (tiles > 0 ? tiles : 1);
+  int sk = by_rows < by_grid ? by_rows : by_grid;
+  return sk < 1 ? 1 : sk;
+}
+
+Layout make_layout(const wgnn_dims* d) {
+  Layout L;
+  L.BT = (size_t)d->B * d->T;
+  L.I = (size_t)d->S * d->F;
+  L.H = d->H;
+  L.G3 = 3 * (size_t)d->H;
+  auto al = [](size_t x) { return align_up(x, 64); };
+  size_t o = 0;
+  L.ws_GI = o; o += al(L.BT * L.G3);
+  L.ws_g = o; o += al(L.BT * L.I);
+  L.fwd_floats = o;
+  o = 0;
+  L.st_g = o; o += al(L.BT * L.I);
+  L.st_gates = o; o += al(L.BT * 4 * L.H);
+  L.stash_floats = o;
+  L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128));
+  L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128));
+  size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
+  size_t part_hh = (size_t)L.sk_hh * L.G3 * (L.H + 1);
+  o = 0;
+  L.ws_dGI = o; o += al(L.BT * L.G3);
+  L.ws_dGH = o; o += al(L.BT * L.G3);
+  L.ws_dg = o; o += al(L.BT * L.I);
+  L.ws_part = o; o += al(part_ih > part_hh ? part_ih : part_hh);
+  L.ws_gcnpart = o; o += al(gcn2_bwd_partial_floats((int)L.BT));
+  L.bwd_floats = o;
+  return L;
+}
+
+int check_dims(const wgnn_dims* d) {
+  if (!d) return WGNN_ERR_NULL;
+  if (d->B < 1 || d->T < 1 || d->S < 1 || d->H < 1) return WGNN_ERR_SHAPE;
+  if (d->F != 13) return WGNN_ERR_SHAPE;            // the reference hard-codes 13 (step6:16)
+  if ((int64_t)d->B * d->T > (1 << 30)) return WGNN_ERR_SHAPE;
+  if (d->adj_format != WGNN_ADJ_DENSE) return WGNN_ERR_UNSUPPORTED;
+  if (d->S > 64) return WGNN_ERR_UNSUPPORTED;       // dense LDS-resident adjacency path
+  if (!gru_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
+  if (d->math != WGNN_MATH_F32) return WGNN_ERR_DTYPE;
+  return WGNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wgnn_version(void) { return WGNN_VERSION; }
+
+const char* wgnn_strerror(int status) {
+  switch (status) {
+    case WGNN_OK: return "ok";
+    case WGNN_ERR_NULL: return "required pointer is NULL";
+    case WGNN_ERR_SHAPE: return "invalid shape (need B,T,S,H >= 1 and F == 13)";
+    case WGNN_ERR_DTYPE: return "unsupported dtype / math mode";
+    case WGNN_ERR_WORKSPACE: return "workspace or stash too small";
+    case WGNN_ERR_UNSUPPORTED: return "configuration not supported by this build (dense S <= 64, H <= 110)";
+    case WGNN_ERR_HIP: return "HIP runtime error (kernel launch failed)";
+    default: return "unknown status";
+  }
+}
+
+size_t wgnn_workspace_bytes(const wgnn_dims* d) {
+  if (check_dims(d) != WGNN_OK) return 0;
+  Layout L = make_layout(d);
+  return sizeof(float) * (L.fwd_floats > L.bwd_floats ? L.fwd_floats : L.bwd_floats);
+}
+
+size_t wgnn_stash_bytes(const wgnn_dims* d) {
+  if (check_dims(d) != WGNN_OK) return 0;
+  return sizeof(float) * make_layout(d).stash_floats;
+}
+
+int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, float* Y, void* stash,
+             void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_dims(d);
+  if (rc != WGNN_OK) return rc;
+  if (!A || !X || !p || !Y || !workspace) return WGNN_ERR_NULL;
+  if (!p->conv1_weight || !p->conv1_bias || !p->conv2_weight || !p->conv2_bias || !p->w_ih || !p->w_hh ||
+      !p->b_ih || !p->b_hh)
+    return WGNN_ERR_NULL;
+  const Layout L = make_layout(d);
+  if (workspace_bytes < sizeof(float) * L.fwd_floats) return WGNN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  float* sf = (float*)stash;
+  float* GI = ws + L.ws_GI;
+  float* g = sf ? sf + L.st_g : ws + L.ws_g;
+  float* gates = sf ? sf + L.st_gates : nullptr;
+
+  rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g, st);
+  if (rc != WGNN_OK) return rc;
+  GemmArgs ga = {};
+  ga.A = g; ga.lda = (int)L.I; ga.a_kcontig = 1;
+  ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
+  ga.C = GI; ga.ldc = (int)L.G3; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
+  ga.bias = p->b_ih; ga.splitk = 1;
+  rc = launch_gemm_f32(ga, st);
+  if (rc != WGNN_OK) return rc;
+  return launch_gru_fwd(d->B, d->T, d->H, GI, p->w_hh, p->b_hh, Y, gates, st);
+}
+
+int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
+             const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
+             void* stream) {
+  int rc = check_dims(d);
+  if (rc != WGNN_OK) return rc;
+  if (!A || !X || !p || !Y || !dY || !stash || !g || !workspace) return WGNN_ERR_NULL;
+  if (!g->conv1_weight || !g->conv1_bias || !g->conv2_weight || !g->conv2_bias || !g->w_ih || !g->w_hh ||
+      !g->b_ih || !g->b_hh)
+    return WGNN_ERR_NULL;
+  const Layout L = make_layout(d);
+  if (workspace_bytes < sizeof(float) * L.bwd_floats) return WGNN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const float* sf = (const float*)stash;
+  const float* gact = sf + L.st_g;
+  const float* gates = sf + L.st_gates;
+  float* dGI = ws + L.ws_dGI;
+  float* dGH = ws + L.ws_dGH;
+  float* dg = ws + L.ws_dg;
+  float* part = ws + L.ws_part;
+
+  rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, st);
+  if (rc != WGNN_OK) return rc;
+
+  // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
+  GemmArgs a = {};
+  a.A = dGH; a.lda = (int)L.G3; a.a_kcontig = 0;
+  a.B = Y; a.ldb = (int)L.H; a.b_kcontig = 0; a.ones_col = 1; a.shift_T = d->T;
+  a.M = (int)L.G3; a.N = (int)L.H + 1; a.K = (int)L.BT;
+  a.splitk = L.sk_hh; a.partial = part;
+  rc = launch_gemm_f32(a, st);
+  if (rc != WGNN_OK) return rc;
+  rc = launch_splitk_reduce(part, L.sk_hh, a.M, a.N, g->w_hh, (int)L.H, (int)L.H, g->b_hh, st);
+  if (rc != WGNN_OK) return rc;
+
+  // dW_ih = dGI^T g, db_ih = dGI^T 1
+  GemmArgs b = {};
+  b.A = dGI; b.lda = (int)L.G3; b.a_kcontig = 0;
+  b.B = gact; b.ldb = (int)L.I; b.b_kcontig = 0; b.ones_col = 1;
+  b.M = (int)L.G3; b.N = (int)L.I + 1; b.K = (int)L.BT;
+  b.splitk = L.sk_ih; b.partial = part;
+  rc = launch_gemm_f32(b, st);
+  if (rc != WGNN_OK) return rc;
+  rc = launch_splitk_reduce(part, L.sk_ih, b.M, b.N, g->w_ih, (int)L.I, (int)L.I, g->b_ih, st);
+  if (rc != WGNN_OK) return rc;
+
+  // dg = dGI W_ih
+  GemmArgs c = {};
+  c.A = dGI; c.lda = (int)L.G3; c.a_kcontig = 1;
+  c.B = p->w_ih; c.ldb = (int)L.I; c.b_kcontig = 0;
+  c.C = dg; c.ldc = (int)L.I; c.M = (int)L.BT; c.N = (int)L.I; c.K = (int)L.G3; c.splitk = 1;
+  rc = launch_gemm_f32(c, st);
+  if (rc != WGNN_OK) return rc;
+
+  return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, dg,
+                         g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);
+}
+
+size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F) {
+  if (ntiles < 1 || S < 1 || S > 64 || F != 13) return 0;
+  return sizeof(float) * gcn1_bwd_partial_floats(ntiles);
+}
+
+int wgnn_gcn_layer_fwd(int32_t ntiles, int32_t S, int32_t F, const float* A, const float* X, const float* W,
+                       const float* b, float* out, void* stream) {
+  if (ntiles < 1 || S < 1 || F != 13) return WGNN_ERR_SHAPE;
+  if (S > 64) return WGNN_ERR_UNSUPPORTED;
+  if (!A || !X || !W || !b || !out) return WGNN_ERR_NULL;
+  return launch_gcn1_fwd(ntiles, S, A, X, W, b, out, (hipStream_t)stream);
+}
+
+int wgnn_gcn_layer_bwd(int32_t ntiles, int32_t S, int32_t F, const float* A, const float* X, const float* W,
+                       const float* out, const float* dout, float* dW, float* db, float* dX, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  if (ntiles < 1 || S < 1 || F != 13) return WGNN_ERR_SHAPE;
+  if (S > 64) return WGNN_ERR_UNSUPPORTED;
+  if (!A || !X || !W || !out || !dout || !dW || !db || !workspace) return WGNN_ERR_NULL;
+  if (workspace_bytes < wgnn_gcn_layer_workspace_bytes(ntiles, S, F)) return WGNN_ERR_WORKSPACE;
+  return launch_gcn1_bwd(ntiles, S, A, X, W, out, dout, dW, db, dX, (float*)workspace, (hipStream_t)stream);
+}
+
+int wgnn_mse_loss_grad(const float* Y, const float* L, int64_t n, float grad_scale, float* dY, float* loss,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!Y || !L || !loss || !workspace) return WGNN_ERR_NULL;
+  if (n < 1) return WGNN_ERR_SHAPE;
+  if (workspace_bytes < 4096) return WGNN_ERR_WORKSPACE;
+  return launch_mse(Y, L, n, grad_scale, dY, loss, (float*)workspace, (hipStream_t)stream);
+}
+
+int wgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                   float lr, float beta1, float beta2, float eps, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq) return WGNN_ERR_NULL;
+  if (n < 1 || step < 1) return WGNN_ERR_SHAPE;
+  return launch_adam(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+}  // extern "C"

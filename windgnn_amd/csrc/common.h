@@ -1,0 +1,78 @@
+// Shared device helpers for the gfx950 kernels of libwindgnn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/windgnn.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WGNN_WAVE 64
+
+static inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#define WGNN_CHECK_LAUNCH()                              \
+  do {                                                   \
+    if (hipGetLastError() != hipSuccess) return WGNN_ERR_HIP; \
+  } while (0)
+
+// v_mfma_f32_16x16x4_f32: A lane l = A[m = l&15][k = l>>4], B lane l = B[k = l>>4][n = l&15],
+// C/D lane l reg r = C[row = 4*(l>>4) + r][col = l&15].  Exact fp32 fmaf chain.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_32x32x2_f32: A lane l = A[i = l&31][k = l>>5], B lane l = B[k = l>>5][j = l&31],
+// C/D lane l reg r = C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // 1 - 2/(e^{2x}+1): exact limits at +-inf, abs error ~1e-7
+  return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f);
+}
+
+// ---- internal launchers (defined in the .hip files, used by api.hip) -------------------------
+struct GemmArgs {
+  const float* A; int lda; int a_kcontig;   // A(m,k) = a_kcontig ? A[m*lda+k] : A[k*lda+m]
+  const float* B; int ldb; int b_kcontig;   // B(k,n) = b_kcontig ? B[n*ldb+k] : B[k*ldb+n]
+  float* C; int ldc;                        // C[m*ldc+n]
+  int M, N, K;
+  const float* bias;                        // optional, added per column n
+  int ones_col;                             // if 1, B gets a virtual extra column N-1 of ones (N includes it)
+  int shift_T;                              // if >0: B row k reads row k-1, rows with k % shift_T == 0 are zero
+  int splitk;                               // >1: partials to `partial` [splitk][M][N], reduce separately
+  float* partial;
+};
+int launch_gemm_f32(const GemmArgs& g, hipStream_t st);
+// C[m*ldc+n] = sum_z partial[z][m][n] for n < ncols_main; bias_out[m] = sum_z partial[z][m][N-1] if bias_out
+int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* C, int ldc,
+                         int ncols_main, float* bias_out, hipStream_t st);
+
+int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,
+                    const float* b1, const float* W2, const float* b2, float* g, hipStream_t st);
+// two-layer backward (no dX): partial buffer >= gcn2_bwd_partial_floats() floats
+size_t gcn2_bwd_partial_floats(int ntiles);
+int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1,
+                    const float* b1, const float* W2, const float* g, const float* dg, float* dW1,
+                    float* db1, float* dW2, float* db2, float* partial, hipStream_t st);
+int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W,
+                    const float* b, float* out, hipStream_t st);
+size_t gcn1_bwd_partial_floats(int ntiles);
+int launch_gcn1_bwd(int ntiles, int S, const float* A, const float* X, const float* W,
+                    const float* out, const float* dout, float* dW, float* db, float* dX,
+                    float* partial, hipStream_t st);
+
+int launch_gru_fwd(int B, int T, int H, const float* GI, const float* Whh, const float* bhh,
+                   float* Y, float* gates /*nullable [B*T][4H]*/, hipStream_t st);
+int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY,
+                   const float* gates, float* dGI, float* dGH, hipStream_t st);
+bool gru_shape_supported(int H);
+
+int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY, float* loss,
+               float* ws, hipStream_t st);
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
+                float b1, float b2, float eps, hipStream_t st);

@@ -1,0 +1,70 @@
+// Call-site ops of the reference training step that sit either side of the hot path:
+//   nn.MSELoss()(outputs, batch_y)      src/main.py:49,72   -> loss and dY = 2 (Y-L) scale / n
+//   torch.optim.Adam(lr=1e-3).step()    src/main.py:52,80   -> flat-buffer Adam
+// Both are HBM-bound elementwise passes; float4 where alignment allows.
+#include "common.h"
+
+namespace {
+
+constexpr int MSE_BLOCKS = 256;
+
+__global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ Y, const float* __restrict__ L,
+                                                  int64_t n, float gscale, float* __restrict__ dY,
+                                                  float* __restrict__ part) {
+  float s = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = Y[i] - L[i];
+    s += d * d;
+    if (dY) dY[i] = d * gscale;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void mse_finalize_kernel(const float* __restrict__ part, int nblk, float inv_n, float* loss) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 64) s += part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2,
+                                                   float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+}
+
+}  // namespace
+
+int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY, float* loss, float* ws,
+               hipStream_t st) {
+  hipLaunchKernelGGL(mse_kernel, dim3(MSE_BLOCKS), dim3(256), 0, st, Y, L, n, 2.0f * scale / (float)n, dY, ws);
+  WGNN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, st, ws, MSE_BLOCKS, 1.0f / (float)n, loss);
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2,
+                float eps, hipStream_t st) {
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
+                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps);
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}

@@ -1,0 +1,178 @@
+"""torch.autograd bindings over the C ABI.  PyTorch is plumbing here: device memory, streams and
+the autograd graph; all arithmetic of the path runs in libwindgnn_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import torch
+
+from . import _lib
+
+PARAM_ORDER = ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias",
+               "gru.weight_ih_l0", "gru.weight_hh_l0", "gru.bias_ih_l0", "gru.bias_hh_l0")
+
+
+def _require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "windgnn_amd runs on an MI355X (HIP) only: got a %s tensor. There is no CPU fallback; "
+                "use the oracle under oracle/ for CPU checks." % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError("windgnn_amd: expected float32 tensors, got %s" % t.dtype)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dims(B, T, S, F, H, math):
+    return _lib.Dims(B, T, S, F, H, math, _lib.ADJ_DENSE, 0)
+
+
+def _params_struct(cls, tensors: Sequence[torch.Tensor]):
+    s = cls()
+    for (name, _), t in zip(cls._fields_, tensors):
+        setattr(s, name, t.data_ptr())
+    return s
+
+
+class _Workspace:
+    """Per-device grow-only scratch, so the steady state does no allocation."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, device, nbytes: int) -> torch.Tensor:
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+
+def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32, want_stash=True):
+    """Y[B,T,H], stash = wgnn_fwd(...).  X is [B,T,S,F]."""
+    lib = _lib.load()
+    _require_gpu(A, X, *params)
+    B, T, S, F = X.shape
+    H = params[5].shape[1]
+    d = _dims(B, T, S, F, H, math)
+    ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
+    if ws_bytes == 0:
+        _lib.check(-5 if F == 13 else -2, "wgnn_workspace_bytes(B=%d,T=%d,S=%d,F=%d,H=%d)" % (B, T, S, F, H))
+    ws = _Workspace.get(X.device, ws_bytes)
+    stash = torch.empty(lib.wgnn_stash_bytes(C.byref(d)), dtype=torch.uint8, device=X.device) if want_stash else None
+    Y = torch.empty(B, T, H, dtype=torch.float32, device=X.device)
+    ps = _params_struct(_lib.Params, params)
+    rc = lib.wgnn_fwd(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(Y), _ptr(stash), _ptr(ws), ws_bytes, _stream())
+    _lib.check(rc, "wgnn_fwd")
+    return Y, stash, d
+
+
+def gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, grads: Sequence[torch.Tensor]):
+    lib = _lib.load()
+    ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
+    ws = _Workspace.get(X.device, ws_bytes)
+    ps = _params_struct(_lib.Params, params)
+    gs = _params_struct(_lib.Grads, grads)
+    rc = lib.wgnn_bwd(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(Y), _ptr(dY), _ptr(stash), C.byref(gs),
+                      _ptr(ws), ws_bytes, _stream())
+    _lib.check(rc, "wgnn_bwd")
+
+
+class GCNGRUFunction(torch.autograd.Function):
+    """Y = GCN_GRU(A, X; 8 params).  Gradients flow to the parameters only: the reference's
+    adjacency and inputs do not require grad (src/main.py:26, src/step4_sequence_preparer.py:58)."""
+
+    @staticmethod
+    def forward(ctx, A, X, math, *params):
+        A = A.contiguous()
+        X = X.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        need = any(ctx.needs_input_grad[3:])
+        Y, stash, d = gcn_gru_forward_raw(A, X, params, math, want_stash=need)
+        ctx.d = d
+        ctx.stash = stash
+        ctx.save_for_backward(A, X, Y, *params)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        A, X, Y, *params = ctx.saved_tensors
+        if ctx.stash is None:
+            raise RuntimeError("windgnn_amd: backward called but the forward ran without a stash")
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=X.device)
+        grads = [g.view_as(p) for g, p in zip(flat.split(sizes), params)]
+        gcn_gru_backward_raw(ctx.d, A, X, params, Y, dY.contiguous(), ctx.stash, grads)
+        return (None, None, None, *grads)
+
+
+def gcn_gru(A, X, params, math=_lib.MATH_F32):
+    return GCNGRUFunction.apply(A, X, math, *params)
+
+
+class GraphConvFunction(torch.autograd.Function):
+    """out = relu(A X W + b) for X [..., S, F] (src/step5_gcn_layer_model.py:13-23)."""
+
+    @staticmethod
+    def forward(ctx, A, X, W, b):
+        lib = _lib.load()
+        _require_gpu(A, X, W, b)
+        A, X, W, b = A.contiguous(), X.contiguous(), W.contiguous(), b.contiguous()
+        S, F = X.shape[-2], X.shape[-1]
+        if A.shape != (S, S):
+            raise RuntimeError("windgnn_amd: adjacency %s does not match %d stations" % (tuple(A.shape), S))
+        nt = X.numel() // (S * F)
+        out = torch.empty_like(X)
+        rc = lib.wgnn_gcn_layer_fwd(nt, S, F, _ptr(A), _ptr(X), _ptr(W), _ptr(b), _ptr(out), _stream())
+        _lib.check(rc, "wgnn_gcn_layer_fwd")
+        ctx.save_for_backward(A, X, W, out)
+        ctx.dims = (nt, S, F)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        A, X, W, out = ctx.saved_tensors
+        nt, S, F = ctx.dims
+        dout = dout.contiguous()
+        dW = torch.empty_like(W)
+        db = torch.empty(F, dtype=torch.float32, device=X.device)
+        dX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
+        nbytes = lib.wgnn_gcn_layer_workspace_bytes(nt, S, F)
+        ws = _Workspace.get(X.device, nbytes)
+        rc = lib.wgnn_gcn_layer_bwd(nt, S, F, _ptr(A), _ptr(X), _ptr(W), _ptr(out), _ptr(dout), _ptr(dW), _ptr(db),
+                                    _ptr(dX), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, "wgnn_gcn_layer_bwd")
+        return None, dX, dW, db
+
+
+def mse_loss_grad(Y, L, grad_scale: float = 1.0, want_grad=True):
+    """loss (0-dim tensor on device) and dY for nn.MSELoss()(Y, L) (src/main.py:49,72)."""
+    lib = _lib.load()
+    _require_gpu(Y, L)
+    Y, L = Y.contiguous(), L.contiguous()
+    if Y.numel() != L.numel():
+        raise RuntimeError("windgnn_amd: MSE operands differ in size: %s vs %s" % (tuple(Y.shape), tuple(L.shape)))
+    dY = torch.empty_like(Y) if want_grad else None
+    loss = torch.empty((), dtype=torch.float32, device=Y.device)
+    ws = _Workspace.get(Y.device, 4096)
+    rc = lib.wgnn_mse_loss_grad(_ptr(Y), _ptr(L), Y.numel(), grad_scale, _ptr(dY), _ptr(loss), _ptr(ws), ws.numel(),
+                                _stream())
+    _lib.check(rc, "wgnn_mse_loss_grad")
+    return loss, dY
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    lib = _lib.load()
+    _require_gpu(param, grad, exp_avg, exp_avg_sq)
+    rc = lib.wgnn_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), step, lr, beta1,
+                            beta2, eps, _stream())
+    _lib.check(rc, "wgnn_adam_step")
