@@ -130,6 +130,15 @@ int wgnn_mse_loss_grad(const float* Y, const float* L, int64_t n, float grad_sca
 int wgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    int32_t step, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* Measurement aid for bench.py (no reference counterpart): while enabled, every kernel launch made
+ * by this library is bracketed by hipEvents on its stream and tallied per kernel symbol together
+ * with its algorithmic flops/bytes.  wgnn_profile_read(idx, ...) synchronises the device and
+ * returns the idx-th kernel's totals, or WGNN_ERR_SHAPE past the end.  Off by default; the only
+ * global state in the library; not thread-safe. */
+int wgnn_profile_enable(int on);
+int wgnn_profile_read(int idx, char* name, size_t name_len, double* total_ms, int64_t* launches,
+                      double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,9 @@ EXPORTS = {
                                      C.c_size_t, C.c_void_p]),
     "wgnn_mse_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wgnn_profile_enable": (C.c_int, [C.c_int]),
+    "wgnn_profile_read": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wgnn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }
@@ -78,3 +81,23 @@ def check(status: int, what: str) -> None:
     if status != 0:
         msg = load().wgnn_strerror(status).decode()
         raise RuntimeError("windgnn_amd: %s failed: %s (status %d)" % (what, msg, status))
+
+
+def profile_enable(on: bool) -> None:
+    check(load().wgnn_profile_enable(1 if on else 0), "wgnn_profile_enable")
+
+
+def profile_read():
+    """[{name, ms, launches, flops, bytes}] accumulated since profile_enable(True)."""
+    lib = load()
+    out = []
+    i = 0
+    while True:
+        name = C.create_string_buffer(128)
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        if lib.wgnn_profile_read(i, name, 128, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)) != 0:
+            break
+        out.append({"name": name.value.decode(), "ms": ms.value, "launches": n.value, "flops": fl.value,
+                    "bytes": by.value})
+        i += 1
+    return out

@@ -35,6 +35,19 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f);
 }
 
+// ---- optional per-kernel timing (hipEvents on the launch stream); off by default ----------------
+// PROF_LAUNCH(name, flops, bytes, st, launch) wraps one kernel launch; algorithmic flops/bytes are
+// what bench.py's roofline uses.  Enabled only through wgnn_profile_enable().
+void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st);
+void prof_end(hipStream_t st);
+extern bool g_prof_on;
+#define PROF_LAUNCH(name, flops, bytes, st, ...) \
+  do {                                            \
+    if (g_prof_on) prof_begin(name, flops, bytes, st); \
+    __VA_ARGS__;                                  \
+    if (g_prof_on) prof_end(st);                  \
+  } while (0)
+
 // ---- internal launchers (defined in the .hip files, used by api.hip) -------------------------
 struct GemmArgs {
   const float* A; int lda; int a_kcontig;   // A(m,k) = a_kcontig ? A[m*lda+k] : A[k*lda+m]

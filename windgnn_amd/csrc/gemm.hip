@@ -139,7 +139,9 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
   p.kchunk = cdiv_i(cdiv_i(g.K, p.splitk), BK) * BK;
   p.partial = g.partial;
   dim3 grid(cdiv_i(g.M, BM), cdiv_i(g.N, BN), p.splitk);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, p);
+  const double fl = 2.0 * g.M * (double)g.N * g.K;
+  const double by = 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N * p.splitk);
+  PROF_LAUNCH("gemm_f32_kernel", fl, by, st, hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, p));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -147,8 +149,9 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
 int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* C, int ldc, int ncols_main,
                          float* bias_out, hipStream_t st) {
   size_t n = (size_t)M * N;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, splitk, M,
-                     N, C, ldc, ncols_main, bias_out);
+  PROF_LAUNCH("splitk_reduce_kernel", (double)n * splitk, 4.0 * n * (splitk + 1), st,
+              hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
+                                 splitk, M, N, C, ldc, ncols_main, bias_out));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

@@ -231,7 +231,10 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, const float* Whh, const
   if (hipFuncSetAttribute((const void*)gru_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
       hipSuccess)
     return WGNN_ERR_HIP;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, GI, Whh, bhh, Y, gates);
+  const double bt = (double)B * T;
+  PROF_LAUNCH("gru_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0)), st,
+              hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, GI, Whh, bhh,
+                                 Y, gates));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -243,8 +246,10 @@ int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const 
   if (hipFuncSetAttribute((const void*)gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
       hipSuccess)
     return WGNN_ERR_HIP;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, Whh, Y, dY, gates, dGI,
-                     dGH);
+  const double bt = (double)B * T;
+  PROF_LAUNCH("gru_bwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (4 * H + 2 * H + 6 * H), st,
+              hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, Whh, Y, dY,
+                                 gates, dGI, dGH));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

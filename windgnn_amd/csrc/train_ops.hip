@@ -52,7 +52,9 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 
 int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY, float* loss, float* ws,
                hipStream_t st) {
-  hipLaunchKernelGGL(mse_kernel, dim3(MSE_BLOCKS), dim3(256), 0, st, Y, L, n, 2.0f * scale / (float)n, dY, ws);
+  PROF_LAUNCH("mse_kernel", 3.0 * n, 12.0 * n, st,
+              hipLaunchKernelGGL(mse_kernel, dim3(MSE_BLOCKS), dim3(256), 0, st, Y, L, n, 2.0f * scale / (float)n, dY,
+                                 ws));
   WGNN_CHECK_LAUNCH();
   hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, st, ws, MSE_BLOCKS, 1.0f / (float)n, loss);
   WGNN_CHECK_LAUNCH();
@@ -63,8 +65,9 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int ste
                 float eps, hipStream_t st) {
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
-                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps);
+  PROF_LAUNCH("adam_kernel", 10.0 * n, 28.0 * n, st,
+              hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
+                                 (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

@@ -1,0 +1,55 @@
+"""Host-side mirror of the reference's training-loop body (src/main.py:64-80) on flat buffers:
+forward -> MSE -> backward -> (data-parallel all-reduce) -> Adam, every op a C-ABI call.
+
+Data parallel: windows are independent, so each rank runs its own shard of
+windows; the 8 gradients live in ONE flat fp32 bucket (167 440 floats at S=34) that is summed
+with a single RCCL all-reduce per step.  dY is pre-scaled by 1/world_size so the summed bucket
+equals the gradient of the big-batch mean loss."""
+from __future__ import annotations
+
+import torch
+
+from .functional import adam_step_, gcn_gru_backward_raw, gcn_gru_forward_raw, mse_loss_grad
+from .modules import GCN_GRU
+
+
+class TrainStep:
+    def __init__(self, model: GCN_GRU, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 process_group=None):
+        self.model = model
+        self.params = list(model.hot_path_parameters())
+        sizes = [p.numel() for p in self.params]
+        dev = self.params[0].device
+        self.flat_p = torch.cat([p.detach().reshape(-1) for p in self.params]).contiguous()
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.p_views, self.g_views = [], []
+        for p, pv, gv in zip(self.params, self.flat_p.split(sizes), self.flat_g.split(sizes)):
+            p.data = pv.view_as(p)              # parameters become views of the flat bucket
+            p.grad = gv.view_as(p)
+            self.p_views.append(p.data)
+            self.g_views.append(p.grad)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.steps = 0
+        self.group = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.device = dev
+
+    def forward_backward(self, A, X, L):
+        """src/main.py:66,72,79: returns (loss, Y); gradients land in the flat bucket."""
+        Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True)
+        loss, dY = mse_loss_grad(Y, L, grad_scale=1.0 / self.world)
+        gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views)
+        return loss, Y
+
+    def step(self, A, X, L):
+        loss, Y = self.forward_backward(A, X, L)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_g, group=self.group)     # RCCL sum over xGMI
+        self.steps += 1
+        adam_step_(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.steps, self.lr,
+                   self.betas[0], self.betas[1], self.eps)                   # src/main.py:80
+        return loss, Y
