@@ -5,50 +5,67 @@
 
 namespace {
 
+inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
 struct Layout {
-  size_t BT, I, G3, H;
-  // forward workspace
-  size_t ws_GI, ws_g, fwd_floats;
+  size_t BT, I, Ip, G3, Gp, H;
+  int np_g3, np_i;                 // padded plane rows of the two split-weight images (f16x3)
+  // forward workspace (float offsets)
+  size_t ws_GI, ws_g, ws_planes_f, fwd_floats;
   // stash
   size_t st_g, st_gates, stash_floats;
   // backward workspace
-  size_t ws_dGI, ws_dGH, ws_dg, ws_part, ws_gcnpart, bwd_floats;
+  size_t ws_dGI, ws_dGH, ws_dg, ws_part, ws_gcnpart, ws_planes_b, ws_scales, bwd_floats;
   int sk_ih, sk_hh;
 };
 
-int pick_splitk(size_t BT, int tiles) {
-  // aim for ~1024 workgroups, at least 256 reduction rows each
-  int by_rows = (int)(BT / 256);
-  int by_grid = 1024 / (tiles > 0 ? tiles : 1);
+int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
+  int by_rows = (int)(BT / (size_t)min_rows);
+  int by_grid = target_wgs / (tiles > 0 ? tiles : 1);
   int sk = by_rows < by_grid ? by_rows : by_grid;
   return sk < 1 ? 1 : sk;
 }
 
 Layout make_layout(const wgnn_dims* d) {
   Layout L;
+  const bool x3 = d->math == WGNN_MATH_F16X3;
   L.BT = (size_t)d->B * d->T;
   L.I = (size_t)d->S * d->F;
+  L.Ip = rup(L.I, 32);
   L.H = d->H;
   L.G3 = 3 * (size_t)d->H;
+  L.Gp = rup(L.G3, 32);
+  L.np_g3 = xgemm_nt_np((int)L.G3);
+  L.np_i = xgemm_nt_np((int)L.I);
   auto al = [](size_t x) { return align_up(x, 64); };
+  const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : 0;   // 2 planes of halfs = that many floats
+  const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : 0;
   size_t o = 0;
   L.ws_GI = o; o += al(L.BT * L.G3);
-  L.ws_g = o; o += al(L.BT * L.I);
+  L.ws_g = o; o += al(L.BT * L.Ip);
+  L.ws_planes_f = o; o += al(planes_f);
   L.fwd_floats = o;
   o = 0;
-  L.st_g = o; o += al(L.BT * L.I);
+  L.st_g = o; o += al(L.BT * L.Ip);
   L.st_gates = o; o += al(L.BT * 4 * L.H);
   L.stash_floats = o;
-  L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128));
-  L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128));
+  if (x3) {
+    L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.I + 1, 128), 256, 64);
+    L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.H + 1, 128), 256, 64);
+  } else {
+    L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128), 1024, 256);
+    L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128), 1024, 256);
+  }
   size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
   size_t part_hh = (size_t)L.sk_hh * L.G3 * (L.H + 1);
   o = 0;
-  L.ws_dGI = o; o += al(L.BT * L.G3);
-  L.ws_dGH = o; o += al(L.BT * L.G3);
+  L.ws_dGI = o; o += al(L.BT * L.Gp);
+  L.ws_dGH = o; o += al(L.BT * L.Gp);
   L.ws_dg = o; o += al(L.BT * L.I);
   L.ws_part = o; o += al(part_ih > part_hh ? part_ih : part_hh);
   L.ws_gcnpart = o; o += al(gcn2_bwd_partial_floats((int)L.BT));
+  L.ws_planes_b = o; o += al(planes_b);
+  L.ws_scales = o; o += al(512);
   L.bwd_floats = o;
   return L;
 }
@@ -61,7 +78,11 @@ int check_dims(const wgnn_dims* d) {
   if (d->adj_format != WGNN_ADJ_DENSE) return WGNN_ERR_UNSUPPORTED;
   if (d->S > 64) return WGNN_ERR_UNSUPPORTED;       // dense LDS-resident adjacency path
   if (!gru_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
-  if (d->math != WGNN_MATH_F32) return WGNN_ERR_DTYPE;
+  if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3) return WGNN_ERR_DTYPE;
+  if (d->math == WGNN_MATH_F16X3) {
+    // split-fp16 GEMM tiles cover all of N in one workgroup: 3H <= 320 (TN) and S*13 <= 448
+    if (3 * d->H > 320 || d->S * d->F > 448) return WGNN_ERR_UNSUPPORTED;
+  }
   return WGNN_OK;
 }
 
@@ -78,7 +99,8 @@ const char* wgnn_strerror(int status) {
     case WGNN_ERR_SHAPE: return "invalid shape (need B,T,S,H >= 1 and F == 13)";
     case WGNN_ERR_DTYPE: return "unsupported dtype / math mode";
     case WGNN_ERR_WORKSPACE: return "workspace or stash too small";
-    case WGNN_ERR_UNSUPPORTED: return "configuration not supported by this build (dense S <= 64, H <= 110)";
+    case WGNN_ERR_UNSUPPORTED:
+      return "configuration not supported by this build (dense S <= 64, H <= 110; f16x3: S <= 34, H <= 106)";
     case WGNN_ERR_HIP: return "HIP runtime error (kernel launch failed)";
     default: return "unknown status";
   }
@@ -111,15 +133,26 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   float* GI = ws + L.ws_GI;
   float* g = sf ? sf + L.st_g : ws + L.ws_g;
   float* gates = sf ? sf + L.st_gates : nullptr;
+  const bool x3 = d->math == WGNN_MATH_F16X3;
 
-  rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g, st);
+  if (x3) {   // split W_ih once per call: 2 fp16 planes [np_g3][Ip]
+    rc = launch_split_weight(p->w_ih, (int)L.G3, (int)L.I, 0, ws + L.ws_planes_f, L.np_g3, (int)L.Ip, st);
+    if (rc != WGNN_OK) return rc;
+  }
+  rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
+                       (int)L.Ip, st);
   if (rc != WGNN_OK) return rc;
-  GemmArgs ga = {};
-  ga.A = g; ga.lda = (int)L.I; ga.a_kcontig = 1;
-  ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
-  ga.C = GI; ga.ldc = (int)L.G3; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
-  ga.bias = p->b_ih; ga.splitk = 1;
-  rc = launch_gemm_f32(ga, st);
+  if (x3) {
+    rc = launch_xgemm_nt(g, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI, (int)L.G3, (int)L.G3,
+                         p->b_ih, nullptr, st);
+  } else {
+    GemmArgs ga = {};
+    ga.A = g; ga.lda = (int)L.Ip; ga.a_kcontig = 1;
+    ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
+    ga.C = GI; ga.ldc = (int)L.G3; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
+    ga.bias = p->b_ih; ga.splitk = 1;
+    rc = launch_gemm_f32(ga, st);
+  }
   if (rc != WGNN_OK) return rc;
   return launch_gru_fwd(d->B, d->T, d->H, GI, p->w_hh, p->b_hh, Y, gates, st);
 }
@@ -144,41 +177,66 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   float* dGH = ws + L.ws_dGH;
   float* dg = ws + L.ws_dg;
   float* part = ws + L.ws_part;
+  float* scales = ws + L.ws_scales;          // [0] = 2^k, [1] = 2^-k (f16x3 range scaling), then 256 partials
+  const bool x3 = d->math == WGNN_MATH_F16X3;
 
-  rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, st);
-  if (rc != WGNN_OK) return rc;
-
-  // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
-  GemmArgs a = {};
-  a.A = dGH; a.lda = (int)L.G3; a.a_kcontig = 0;
-  a.B = Y; a.ldb = (int)L.H; a.b_kcontig = 0; a.ones_col = 1; a.shift_T = d->T;
-  a.M = (int)L.G3; a.N = (int)L.H + 1; a.K = (int)L.BT;
-  a.splitk = L.sk_hh; a.partial = part;
-  rc = launch_gemm_f32(a, st);
-  if (rc != WGNN_OK) return rc;
-  rc = launch_splitk_reduce(part, L.sk_hh, a.M, a.N, g->w_hh, (int)L.H, (int)L.H, g->b_hh, st);
+  if (x3) {
+    rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);
+    if (rc != WGNN_OK) return rc;
+  }
+  rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
   if (rc != WGNN_OK) return rc;
 
-  // dW_ih = dGI^T g, db_ih = dGI^T 1
-  GemmArgs b = {};
-  b.A = dGI; b.lda = (int)L.G3; b.a_kcontig = 0;
-  b.B = gact; b.ldb = (int)L.I; b.b_kcontig = 0; b.ones_col = 1;
-  b.M = (int)L.G3; b.N = (int)L.I + 1; b.K = (int)L.BT;
-  b.splitk = L.sk_ih; b.partial = part;
-  rc = launch_gemm_f32(b, st);
-  if (rc != WGNN_OK) return rc;
-  rc = launch_splitk_reduce(part, L.sk_ih, b.M, b.N, g->w_ih, (int)L.I, (int)L.I, g->b_ih, st);
-  if (rc != WGNN_OK) return rc;
+  if (x3) {
+    // dW_hh = dGH^T [Hprev | 1]
+    rc = launch_xgemm_tn(dGH, (int)L.Gp, (int)L.G3, Y, (int)L.H, (int)L.H, (int)L.H, d->T, (int)L.BT, L.sk_hh, part,
+                         (int)L.G3, (int)L.H + 1, scales, st);
+    if (rc != WGNN_OK) return rc;
+    rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales, st);
+    if (rc != WGNN_OK) return rc;
+    // dW_ih = dGI^T [g | 1]
+    rc = launch_xgemm_tn(dGI, (int)L.Gp, (int)L.G3, gact, (int)L.Ip, (int)L.I, (int)L.I, 0, (int)L.BT, L.sk_ih, part,
+                         (int)L.G3, (int)L.I + 1, scales, st);
+    if (rc != WGNN_OK) return rc;
+    rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales, st);
+    if (rc != WGNN_OK) return rc;
+    // dg = dGI W_ih  (B operand = split(W_ih^T) [np_i][Gp])
+    rc = launch_split_weight(p->w_ih, (int)L.G3, (int)L.I, 1, ws + L.ws_planes_b, L.np_i, (int)L.Gp, st);
+    if (rc != WGNN_OK) return rc;
+    rc = launch_xgemm_nt(dGI, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I, (int)L.I,
+                         nullptr, scales, st);
+    if (rc != WGNN_OK) return rc;
+  } else {
+    // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
+    GemmArgs a = {};
+    a.A = dGH; a.lda = (int)L.Gp; a.a_kcontig = 0;
+    a.B = Y; a.ldb = (int)L.H; a.b_kcontig = 0; a.ones_col = 1; a.shift_T = d->T;
+    a.M = (int)L.G3; a.N = (int)L.H + 1; a.K = (int)L.BT;
+    a.splitk = L.sk_hh; a.partial = part;
+    rc = launch_gemm_f32(a, st);
+    if (rc != WGNN_OK) return rc;
+    rc = launch_splitk_reduce(part, L.sk_hh, a.M, a.N, g->w_hh, (int)L.H, (int)L.H, g->b_hh, nullptr, st);
+    if (rc != WGNN_OK) return rc;
+    // dW_ih = dGI^T g, db_ih = dGI^T 1
+    GemmArgs b = {};
+    b.A = dGI; b.lda = (int)L.Gp; b.a_kcontig = 0;
+    b.B = gact; b.ldb = (int)L.Ip; b.b_kcontig = 0; b.ones_col = 1;
+    b.M = (int)L.G3; b.N = (int)L.I + 1; b.K = (int)L.BT;
+    b.splitk = L.sk_ih; b.partial = part;
+    rc = launch_gemm_f32(b, st);
+    if (rc != WGNN_OK) return rc;
+    rc = launch_splitk_reduce(part, L.sk_ih, b.M, b.N, g->w_ih, (int)L.I, (int)L.I, g->b_ih, nullptr, st);
+    if (rc != WGNN_OK) return rc;
+    // dg = dGI W_ih
+    GemmArgs c = {};
+    c.A = dGI; c.lda = (int)L.Gp; c.a_kcontig = 1;
+    c.B = p->w_ih; c.ldb = (int)L.I; c.b_kcontig = 0;
+    c.C = dg; c.ldc = (int)L.I; c.M = (int)L.BT; c.N = (int)L.I; c.K = (int)L.G3; c.splitk = 1;
+    rc = launch_gemm_f32(c, st);
+    if (rc != WGNN_OK) return rc;
+  }
 
-  // dg = dGI W_ih
-  GemmArgs c = {};
-  c.A = dGI; c.lda = (int)L.G3; c.a_kcontig = 1;
-  c.B = p->w_ih; c.ldb = (int)L.I; c.b_kcontig = 0;
-  c.C = dg; c.ldc = (int)L.I; c.M = (int)L.BT; c.N = (int)L.I; c.K = (int)L.G3; c.splitk = 1;
-  rc = launch_gemm_f32(c, st);
-  if (rc != WGNN_OK) return rc;
-
-  return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, dg,
+  return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                          g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);
 }
 

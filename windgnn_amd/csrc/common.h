@@ -63,14 +63,25 @@ struct GemmArgs {
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st);
 // C[m*ldc+n] = sum_z partial[z][m][n] for n < ncols_main; bias_out[m] = sum_z partial[z][m][N-1] if bias_out
 int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* C, int ldc,
-                         int ncols_main, float* bias_out, hipStream_t st);
+                         int ncols_main, float* bias_out, const float* scales /*nullable: *= scales[1]*/,
+                         hipStream_t st);
+
+// split-fp16 MFMA GEMMs (xgemm.hip)
+int launch_split_weight(const float* W, int R, int C, int transpose, void* planes, int Rp, int Cp, hipStream_t st);
+int launch_amax_scale(const float* x, int64_t n, float* scales, float* part, hipStream_t st);
+int xgemm_nt_np(int N);   // padded row count of the B planes for N output columns, -1 if unsupported
+int launch_xgemm_nt(const float* A, int lda, int M, int Kp, const void* Bplanes, int Np, float* C, int ldc, int N,
+                    const float* bias, const float* scales, hipStream_t st);
+int launch_xgemm_tn(const float* A, int lda, int mcols, const float* B, int ldb, int ncols_b, int ones_col,
+                    int shift_T, int K, int splitk, float* partial, int Mout, int Nout, const float* scales,
+                    hipStream_t st);
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,
-                    const float* b1, const float* W2, const float* b2, float* g, hipStream_t st);
+                    const float* b1, const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
 // two-layer backward (no dX): partial buffer >= gcn2_bwd_partial_floats() floats
 size_t gcn2_bwd_partial_floats(int ntiles);
 int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1,
-                    const float* b1, const float* W2, const float* g, const float* dg, float* dW1,
+                    const float* b1, const float* W2, const float* g, int ldg, const float* dg, float* dW1,
                     float* db1, float* dW2, float* db2, float* partial, hipStream_t st);
 int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W,
                     const float* b, float* out, hipStream_t st);
@@ -82,7 +93,7 @@ int launch_gcn1_bwd(int ntiles, int S, const float* A, const float* X, const flo
 int launch_gru_fwd(int B, int T, int H, const float* GI, const float* Whh, const float* bhh,
                    float* Y, float* gates /*nullable [B*T][4H]*/, hipStream_t st);
 int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY,
-                   const float* gates, float* dGI, float* dGH, hipStream_t st);
+                   const float* gates, float* dGI, float* dGH, int ldd, hipStream_t st);
 bool gru_shape_supported(int H);
 
 int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY, float* loss,

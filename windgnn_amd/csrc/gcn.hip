@@ -104,7 +104,8 @@ template <int LAYERS>
 __global__ void __launch_bounds__(256) gcn_fwd_kernel(int ntiles, int S, int F, const float* __restrict__ A,
                                                       const float* __restrict__ X, const float* __restrict__ W1,
                                                       const float* __restrict__ b1, const float* __restrict__ W2,
-                                                      const float* __restrict__ b2, float* __restrict__ out) {
+                                                      const float* __restrict__ b2, float* __restrict__ out,
+                                                      int ld_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GcnGeom G(S);
   float* As = smem;
@@ -165,8 +166,9 @@ __global__ void __launch_bounds__(256) gcn_fwd_kernel(int ntiles, int S, int F, 
       __syncthreads();
     }
     if (valid) {
-      float* dst = out + (size_t)tile * I;
+      float* dst = out + (size_t)tile * ld_out;
       for (int i = L.lane; i < I; i += 64) dst[i] = Hs[(i / F) * RS + (i % F)];
+      for (int i = I + L.lane; i < ld_out; i += 64) dst[i] = 0.f;   // K padding of the projection GEMM
     }
     __syncthreads();
   }
@@ -184,7 +186,8 @@ __global__ void __launch_bounds__(256) gcn_bwd_kernel(int ntiles, int S, int F, 
                                                       const float* __restrict__ X, const float* __restrict__ W1,
                                                       const float* __restrict__ b1, const float* __restrict__ W2,
                                                       const float* __restrict__ gout, const float* __restrict__ dgout,
-                                                      float* __restrict__ dX, float* __restrict__ partial) {
+                                                      float* __restrict__ dX, float* __restrict__ partial,
+                                                      int ld_g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GcnGeom G(S);
   float* As = smem;
@@ -216,8 +219,9 @@ __global__ void __launch_bounds__(256) gcn_bwd_kernel(int ntiles, int S, int F, 
     const bool valid = tile < ntiles;
     const size_t off = (size_t)(valid ? tile : 0) * I;
     load_tile(Xs, X + off, S, F, L.lane, valid);
+    const size_t goff = (size_t)(valid ? tile : 0) * ld_g;
     for (int i = L.lane; i < I; i += 64) {   // dZ_last = dout * (out > 0)
-      float v = (valid && gout[off + i] > 0.f) ? dgout[off + i] : 0.f;
+      float v = (valid && gout[goff + i] > 0.f) ? dgout[off + i] : 0.f;
       Ds[(i / F) * RS + (i % F)] = v;
     }
     __syncthreads();
@@ -343,12 +347,12 @@ size_t gcn2_bwd_partial_floats(int ntiles) { return (size_t)grid_for(ntiles) * P
 size_t gcn1_bwd_partial_floats(int ntiles) { return (size_t)grid_for(ntiles) * PART; }
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                    const float* W2, const float* b2, float* g, hipStream_t st) {
+                    const float* W2, const float* b2, float* g, int ldg, hipStream_t st) {
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
   const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
   PROF_LAUNCH("gcn_fwd_kernel<2>", fl, by, st,
               hipLaunchKernelGGL(gcn_fwd_kernel<2>, dim3(grid_for(ntiles)), dim3(256), smem_bytes(S), st, ntiles, S,
-                                 13, A, X, W1, b1, W2, b2, g));
+                                 13, A, X, W1, b1, W2, b2, g, ldg));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -356,13 +360,13 @@ int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const flo
 int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W, const float* b, float* out,
                     hipStream_t st) {
   hipLaunchKernelGGL(gcn_fwd_kernel<1>, dim3(grid_for(ntiles)), dim3(256), smem_bytes(S), st, ntiles, S, 13, A, X, W,
-                     b, (const float*)nullptr, (const float*)nullptr, out);
+                     b, (const float*)nullptr, (const float*)nullptr, out, S * 13);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
 
 int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                    const float* W2, const float* g, const float* dg, float* dW1, float* db1, float* dW2,
+                    const float* W2, const float* g, int ldg, const float* dg, float* dW1, float* db1, float* dW2,
                     float* db2, float* partial, hipStream_t st) {
   int grid = grid_for(ntiles);
   // algorithmic: recompute of layer 1 + both layers' backward (64 532 flop per tile at S=34)
@@ -370,7 +374,7 @@ int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const flo
   const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
   PROF_LAUNCH("gcn_bwd_kernel<2>", fl, by, st,
               hipLaunchKernelGGL(gcn_bwd_kernel<2>, dim3(grid), dim3(256), smem_bytes(S), st, ntiles, S, 13, A, X, W1,
-                                 b1, W2, g, dg, (float*)nullptr, partial));
+                                 b1, W2, g, dg, (float*)nullptr, partial, ldg));
   WGNN_CHECK_LAUNCH();
   hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 256)), dim3(256), 0, st, partial, grid, 13, dW1,
                      db1, dW2, db2);
@@ -382,7 +386,7 @@ int launch_gcn1_bwd(int ntiles, int S, const float* A, const float* X, const flo
                     const float* dout, float* dW, float* db, float* dX, float* partial, hipStream_t st) {
   int grid = grid_for(ntiles);
   hipLaunchKernelGGL(gcn_bwd_kernel<1>, dim3(grid), dim3(256), smem_bytes(S), st, ntiles, S, 13, A, X, W,
-                     (const float*)nullptr, (const float*)nullptr, out, dout, dX, partial);
+                     (const float*)nullptr, (const float*)nullptr, out, dout, dX, partial, S * 13);
   WGNN_CHECK_LAUNCH();
   hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 256)), dim3(256), 0, st, partial, grid, 13, dW,
                      db, (float*)nullptr, (float*)nullptr);

@@ -117,11 +117,13 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splitk, int M, int N,
-                                     float* __restrict__ C, int ldc, int ncols_main, float* __restrict__ bias_out) {
+                                     float* __restrict__ C, int ldc, int ncols_main, float* __restrict__ bias_out,
+                                     const float* __restrict__ scales) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * N) return;
   float s = 0.f;
   for (int z = 0; z < splitk; ++z) s += partial[(size_t)z * M * N + i];
+  if (scales) s *= scales[1];
   int m = (int)(i / N), n = (int)(i % N);
   if (n < ncols_main) C[(size_t)m * ldc + n] = s;
   else if (bias_out && n == N - 1) bias_out[m] = s;
@@ -147,11 +149,11 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
 }
 
 int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* C, int ldc, int ncols_main,
-                         float* bias_out, hipStream_t st) {
+                         float* bias_out, const float* scales, hipStream_t st) {
   size_t n = (size_t)M * N;
   PROF_LAUNCH("splitk_reduce_kernel", (double)n * splitk, 4.0 * n * (splitk + 1), st,
               hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
-                                 splitk, M, N, C, ldc, ncols_main, bias_out));
+                                 splitk, M, N, C, ldc, ncols_main, bias_out, scales));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, 
 __global__ void __launch_bounds__(NTHREADS) gru_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
                                                            const float* __restrict__ Y, const float* __restrict__ dY,
                                                            const float* __restrict__ gates, float* __restrict__ dGI,
-                                                           float* __restrict__ dGH) {
+                                                           float* __restrict__ dGH, int ldd) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GruGeom G(H);
   float* Ws = smem;
@@ -150,6 +150,15 @@ __global__ void __launch_bounds__(NTHREADS) gru_bwd_kernel(int B, int T, int H, 
   const int jc = jv ? j : H - 1;
   const int b0 = blockIdx.x * MB;
   const int G3 = 3 * H;
+  {  // zero the K-padding columns [3H, ldd) of this workgroup's dGI/dGH rows
+    const int npad = ldd - G3;
+    const int nrows = min(MB, B - b0) * T;
+    for (int i = threadIdx.x; i < nrows * npad; i += NTHREADS) {
+      const size_t o = ((size_t)b0 * T + i / npad) * ldd + G3 + i % npad;
+      dGI[o] = 0.f;
+      dGH[o] = 0.f;
+    }
+  }
 
   struct StepIn { float dy[4], r[4], z[4], n[4], ghn[4], hp[4]; };
   auto load_step = [&](int t, StepIn& s) {
@@ -195,8 +204,8 @@ __global__ void __launch_bounds__(NTHREADS) gru_bwd_kernel(int B, int T, int H, 
         ds[m * G.DS + 2 * H + j] = dnr;
         if (b < B) {
           const size_t bt = (size_t)b * T + t;
-          float* gi = dGI + bt * G3;
-          float* gh = dGH + bt * G3;
+          float* gi = dGI + bt * ldd;
+          float* gh = dGH + bt * ldd;
           gi[j] = dar; gi[H + j] = daz; gi[2 * H + j] = dnt;
           gh[j] = dar; gh[H + j] = daz; gh[2 * H + j] = dnr;
         }
@@ -240,7 +249,7 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, const float* Whh, const
 }
 
 int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
-                   float* dGI, float* dGH, hipStream_t st) {
+                   float* dGI, float* dGH, int ldd, hipStream_t st) {
   GruGeom G(H);
   size_t smem = G.bwd_bytes();
   if (hipFuncSetAttribute((const void*)gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
@@ -249,7 +258,7 @@ int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const 
   const double bt = (double)B * T;
   PROF_LAUNCH("gru_bwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (4 * H + 2 * H + 6 * H), st,
               hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, Whh, Y, dY,
-                                 gates, dGI, dGH));
+                                 gates, dGI, dGH, ldd));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
