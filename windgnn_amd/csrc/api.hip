@@ -63,7 +63,10 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_dGH = o; o += al(L.BT * L.Gp);
   L.ws_dg = o; o += al(L.BT * L.I);
   L.ws_part = o; o += al(part_ih > part_hh ? part_ih : part_hh);
-  L.ws_gcnpart = o; o += al(gcn2_bwd_partial_floats((int)L.BT));
+  {
+    size_t a = gcn2_bwd_partial_floats((int)L.BT), b = gcnx2_bwd_partial_floats((int)L.BT);
+    L.ws_gcnpart = o; o += al(a > b ? a : b);
+  }
   L.ws_planes_b = o; o += al(planes_b);
   L.ws_scales = o; o += al(512);
   L.bwd_floats = o;
@@ -139,8 +142,12 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     rc = launch_split_weight(p->w_ih, (int)L.G3, (int)L.I, 0, ws + L.ws_planes_f, L.np_g3, (int)L.Ip, st);
     if (rc != WGNN_OK) return rc;
   }
-  rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                       (int)L.Ip, st);
+  if (x3)
+    rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
+                          (int)L.Ip, st);
+  else
+    rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
+                         (int)L.Ip, st);
   if (rc != WGNN_OK) return rc;
   if (x3) {
     rc = launch_xgemm_nt(g, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI, (int)L.G3, (int)L.G3,
@@ -236,6 +243,13 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     if (rc != WGNN_OK) return rc;
   }
 
+  if (x3) {
+    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
+                          scales, ws + L.ws_gcnpart, st);
+    if (rc != WGNN_OK) return rc;
+    return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT), g->conv1_weight, g->conv1_bias,
+                                     g->conv2_weight, g->conv2_bias, st);
+  }
   return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                          g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);
 }

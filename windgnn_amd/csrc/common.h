@@ -83,6 +83,16 @@ size_t gcn2_bwd_partial_floats(int ntiles);
 int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1,
                     const float* b1, const float* W2, const float* g, int ldg, const float* dg, float* dW1,
                     float* db1, float* dW2, float* db2, float* partial, hipStream_t st);
+int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
+                              hipStream_t st);
+// register-chained split-fp16 variants (gcnx.hip)
+size_t gcnx2_bwd_partial_floats(int ntiles);
+int gcnx_bwd_grid(int ntiles);
+int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+                     const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
+int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+                     const float* W2, const float* g, int ldg, const float* dg, const float* scales, float* partial,
+                     hipStream_t st);
 int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W,
                     const float* b, float* out, hipStream_t st);
 size_t gcn1_bwd_partial_floats(int ntiles);

@@ -343,6 +343,14 @@ size_t smem_bytes(int S) {
 
 }  // namespace
 
+int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 256)), dim3(256), 0, st, partial, nblk, 13, dW1,
+                     db1, dW2, db2);
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
 size_t gcn2_bwd_partial_floats(int ntiles) { return (size_t)grid_for(ntiles) * PART; }
 size_t gcn1_bwd_partial_floats(int ntiles) { return (size_t)grid_for(ntiles) * PART; }
 

@@ -1,0 +1,485 @@
+// Two-layer graph convolution, split-fp16 ("f16x3") MFMA, register-chained.
+//
+// Reference: the two GraphConvLayer calls of GCN_GRU.forward
+// (src/step6_gcn_gru_combined_model.py:17-20; layer = src/step5_gcn_layer_model.py:13-23) and
+// their autograd backward (src/main.py:79).
+//
+// One wavefront owns one (window, timestep) tile X_t [S,13] end to end and never touches LDS in the
+// forward: every product is a v_mfma_f32_16x16x32_f16 whose accumulator tile (C layout: lane =
+// column, 4 registers = 4 consecutive rows) is converted to fp16 hi/lo in registers and fed straight
+// back as the A or B operand of the next product.  That works for any product that contracts over
+// the ROW index of the accumulator stack; the constant operand (A, A^T, W) is pre-permuted once per
+// wave to the k-order the accumulator registers impose:
+//     k-slot (g = lane>>4, j) of K-step ks  <->  row rho = 16*(2*ks + (j>>2)) + 4*g + (j&3).
+//
+// Forward chain (all [rows][cols<=16] stacks):
+//   U1[s'][f'] = X W1            X loaded straight from HBM as the A operand (natural k = f)
+//   H1t[f][s]  = relu(U1^T A^T + b1)        (U1 as A operand, contraction over s')
+//   U2[s][f']  = H1 W2                     (H1t as A operand, contraction over f)
+//   g[s][f']   = relu(A U2 + b2), produced as g^T[f'][s] and stored station-major.
+// Backward chain: see gcnx_bwd_kernel.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int F13 = 13;
+constexpr int FP = 16;
+constexpr int PART = 2 * FP * FP + 2 * FP;   // same partial layout as gcn.hip
+
+struct Frag { h8 hi, lo; };
+
+__device__ __forceinline__ f32x4 mfma_x(h8 a, h8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
+  c = mfma_x(a.lo, b.hi, c);
+  c = mfma_x(a.hi, b.lo, c);
+  c = mfma_x(a.hi, b.hi, c);
+  return c;
+}
+__device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
+  Frag f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 h = (_Float16)x[j];
+    f.hi[j] = h;
+    f.lo[j] = (_Float16)(x[j] - (float)h);
+  }
+  return f;
+}
+// operand fragment from two stacked accumulator row-tiles (slots j<4 from t0, j>=4 from t1)
+__device__ __forceinline__ Frag frag_of(f32x4 t0, f32x4 t1) {
+  const float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+  return split_vals(x);
+}
+__device__ __forceinline__ int rho(int ks, int g, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3); }
+
+// "A [m = s][k = s']" fragments in rho order (also the B operand of any product with A^T)
+template <int NT, int KS, bool TRANSPOSE>
+__device__ __forceinline__ void build_A_frags(Frag (&CA)[NT][KS], const float* __restrict__ A, int S, int c, int g) {
+#pragma unroll
+  for (int mi = 0; mi < NT; ++mi)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int m = 16 * mi + c, k = rho(ks, g, j);
+        float v = 0.f;
+        if (m < S && k < S) v = TRANSPOSE ? A[k * S + m] : A[m * S + k];
+        x[j] = v;
+      }
+      CA[mi][ks] = split_vals(x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-wave LDS staging: a tile's S*13 floats are moved HBM <-> LDS with fully coalesced dword
+// accesses (element i = lane + 64k) and laid out [station][XS] so that fragment reads are aligned
+// ds_read_b128 (natural k = f) or ds_read_b32 (C layout).  Each wave owns its buffers; ordering
+// between its own LDS writes and reads needs no s_barrier, only a fence the compiler respects.
+constexpr int XS = 20;   // row stride in floats: 16-B aligned rows, spreads rows over banks
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int NE>
+struct LinMap {            // element i = lane + 64k of a linear [S*13] tile <-> LDS offset s*XS + f
+  int off[NE];
+  __device__ __forceinline__ void init(int lane, int I) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = lane + 64 * k;
+      const int ic = i < I ? i : 0;
+      off[k] = (ic / F13) * XS + (ic % F13);
+    }
+  }
+};
+
+template <int NE>
+__device__ __forceinline__ void gload_lin(float (&r)[NE], const float* __restrict__ src, int lane, int I) {
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int i = lane + 64 * k;
+    r[k] = src[i < I ? i : I - 1];            // clamped, unconditional: no exec-mask branches
+  }
+}
+
+// A-operand fragment (natural k = f) of X rows 16i + c from the staged tile
+__device__ __forceinline__ Frag xfrag_nat(const float* xb, int i, int c, int g) {
+  const f32x4 v0 = *(const f32x4*)(xb + (16 * i + c) * XS + 8 * (g & 1));
+  const f32x4 v1 = *(const f32x4*)(xb + (16 * i + c) * XS + 8 * (g & 1) + 4);
+  const bool on = g < 2;                       // k = 8g + j >= 16 for g >= 2: zero
+  const float x[8] = {on ? v0[0] : 0.f, on ? v0[1] : 0.f, on ? v0[2] : 0.f, on ? v0[3] : 0.f,
+                      on ? v1[0] : 0.f, on ? v1[1] : 0.f, on ? v1[2] : 0.f, on ? v1[3] : 0.f};
+  return split_vals(x);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
+                                                       const float* __restrict__ X, const float* __restrict__ W1,
+                                                       const float* __restrict__ b1, const float* __restrict__ W2,
+                                                       const float* __restrict__ b2, float* __restrict__ out,
+                                                       int ld_out) {
+  constexpr int KS = (NT + 1) / 2;
+  constexpr int SP = 16 * NT;
+  constexpr int NE = (SP * F13 + 63) / 64;
+  __shared__ __attribute__((aligned(16))) float sbuf[4 * 2 * SP * XS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int I = S * F13;
+  float* xb = sbuf + wave * 2 * SP * XS;
+  float* ob = xb + SP * XS;
+  for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;   // pads (f >= 13, s >= S) stay zero forever
+
+  Frag CA[NT][KS];
+  build_A_frags<NT, KS, false>(CA, A, S, c, g);
+  Frag FW1, FW2;
+  float bb1[4], bb2[4];
+  {
+    float x1[8], x2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = 8 * g + j;                       // natural k = f for X W1
+      x1[j] = (f < F13 && c < F13) ? W1[f * F13 + c] : 0.f;
+      const int f2 = 4 * g + j;                      // rho order over one 16-row tile for H1 W2
+      x2[j] = (j < 4 && f2 < F13 && c < F13) ? W2[f2 * F13 + c] : 0.f;
+    }
+    FW1 = split_vals(x1);
+    FW2 = split_vals(x2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 4 * g + r;
+      bb1[r] = f < F13 ? b1[f] : 0.f;
+      bb2[r] = f < F13 ? b2[f] : 0.f;
+    }
+  }
+  LinMap<NE> map;
+  map.init(lane, I);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+
+  float xr[NE];
+  if (wave_id < ntiles) gload_lin<NE>(xr, X + (size_t)wave_id * I, lane, I);
+  for (int tile = wave_id; tile < ntiles; tile += nwaves) {
+    wave_lds_fence();                                 // previous tile's LDS reads are done
+#pragma unroll
+    for (int k = 0; k < NE; ++k)
+      if (lane + 64 * k < I) xb[map.off[k]] = xr[k];
+    wave_lds_fence();
+    if (tile + nwaves < ntiles) gload_lin<NE>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch
+
+    f32x4 U[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) U[i] = mfma3(xfrag_nat(xb, i, c, g), FW1, zero4);   // U1 row-tile i
+    Frag UF[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+    f32x4 Ht[NT];                                    // H1^T column-tile n: [f][s = 16n + c]
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3(UF[ks], CA[n][ks], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ht[n][r] = fmaxf(acc[r] + bb1[r], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) U[i] = mfma3(frag_of(Ht[i], zero4), FW2, zero4);   // U2 row-tile i [s][f']
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3(UF[ks], CA[n][ks], acc);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bb2[r], 0.f);
+      *(f32x4*)(ob + (16 * n + c) * XS + 4 * g) = v;           // g^T[f' = 4g..4g+3][s] -> staged [s][f']
+    }
+    wave_lds_fence();
+    float* dst = out + (size_t)tile * ld_out;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = lane + 64 * k;
+      if (i < I) dst[i] = ob[map.off[k]];
+    }
+    for (int i = I + lane; i < ld_out; i += 64) dst[i] = 0.f;   // K padding of the projection GEMM
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of both layers for one tile (no dX: the input does not require grad).  With
+//   U1 = X W1, H1 = relu(A U1 + b1)      (recomputed),  dZ2 = dg * (g > 0) * scale
+//   dU2 = A^T dZ2                 dW2 += H1^T dU2        db2 += colsum(dZ2)
+//   dU2t = dZ2^T A  (= dU2^T)     dH1 = dU2 W2^T         dZ1 = dH1 * (H1 > 0)
+//   dU1 = A^T dZ1                 dW1 += X^T dU1         db1 += colsum(dZ1)
+// every product contracts over the row index of an accumulator stack (or of a tile staged in LDS and
+// read in C layout).  A and A^T fragments live in LDS (shared by the 4 waves); dg is scaled by the
+// power of two scales[0] so fp16 never sees ~1e-9 values and the partial sums are un-scaled by
+// scales[1] at the end.
+template <int NT>
+__global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
+                                                       const float* __restrict__ X, const float* __restrict__ W1,
+                                                       const float* __restrict__ b1, const float* __restrict__ W2,
+                                                       const float* __restrict__ gact, int ld_g,
+                                                       const float* __restrict__ dg, const float* __restrict__ scales,
+                                                       float* __restrict__ partial) {
+  constexpr int KS = (NT + 1) / 2;
+  constexpr int NF = NT * KS;
+  constexpr int SP = 16 * NT;
+  constexpr int NE = (SP * F13 + 63) / 64;
+  __shared__ __attribute__((aligned(16))) h8 sCA[2 * NF * 64];   // [frag][hi|lo][lane]
+  __shared__ __attribute__((aligned(16))) h8 sCT[2 * NF * 64];
+  __shared__ __attribute__((aligned(16))) float sbuf[4 * 2 * SP * XS];
+  __shared__ float red[4 * PART];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int I = S * F13;
+  float* xb = sbuf + wave * 2 * SP * XS;
+  float* db = xb + SP * XS;
+  for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;
+  if (wave == 0) {
+    Frag T[NT][KS];
+    build_A_frags<NT, KS, false>(T, A, S, c, g);
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sCA[((mi * KS + ks) * 2 + 0) * 64 + lane] = T[mi][ks].hi;
+        sCA[((mi * KS + ks) * 2 + 1) * 64 + lane] = T[mi][ks].lo;
+      }
+  } else if (wave == 1) {
+    Frag T[NT][KS];
+    build_A_frags<NT, KS, true>(T, A, S, c, g);
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sCT[((mi * KS + ks) * 2 + 0) * 64 + lane] = T[mi][ks].hi;
+        sCT[((mi * KS + ks) * 2 + 1) * 64 + lane] = T[mi][ks].lo;
+      }
+  }
+  __syncthreads();
+  auto ldA = [&](int mi, int ks) {
+    Frag f;
+    f.hi = sCA[((mi * KS + ks) * 2 + 0) * 64 + lane];
+    f.lo = sCA[((mi * KS + ks) * 2 + 1) * 64 + lane];
+    return f;
+  };
+  auto ldT = [&](int mi, int ks) {
+    Frag f;
+    f.hi = sCT[((mi * KS + ks) * 2 + 0) * 64 + lane];
+    f.lo = sCT[((mi * KS + ks) * 2 + 1) * 64 + lane];
+    return f;
+  };
+
+  Frag FW1, FW2T;
+  {
+    float x1[8], x2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = 8 * g + j;
+      x1[j] = (f < F13 && c < F13) ? W1[f * F13 + c] : 0.f;
+      const int fp = 4 * g + j;                      // k = f' (rho order, one tile), n = c = f: W2^T[f'][f]
+      x2[j] = (j < 4 && fp < F13 && c < F13) ? W2[c * F13 + fp] : 0.f;
+    }
+    FW1 = split_vals(x1);
+    FW2T = split_vals(x2);
+  }
+  const float bias1 = c < F13 ? b1[c] : 0.f;         // H1 is [s][f] here: bias per column
+  const float s_in = scales ? scales[0] : 1.f, s_out = scales ? scales[1] : 1.f;
+  LinMap<NE> map;
+  map.init(lane, I);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+
+  f32x4 dW1acc = zero4, dW2acc = zero4;
+  float db1acc = 0.f, db2acc = 0.f;
+
+  float xr[NE], gr[NE], dr[NE];
+  if (wave_id < ntiles) {
+    gload_lin<NE>(xr, X + (size_t)wave_id * I, lane, I);
+    gload_lin<NE>(gr, gact + (size_t)wave_id * ld_g, lane, I);
+    gload_lin<NE>(dr, dg + (size_t)wave_id * I, lane, I);
+  }
+  for (int tile = wave_id; tile < ntiles; tile += nwaves) {
+    asm volatile("" ::: "memory");   // keep the A / A^T fragment reads in LDS (no hoisting into 96 VGPRs)
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NE; ++k)
+      if (lane + 64 * k < I) {
+        xb[map.off[k]] = xr[k];
+        db[map.off[k]] = gr[k] > 0.f ? dr[k] * s_in : 0.f;     // dZ2 = dg * (g > 0), range-scaled
+      }
+    wave_lds_fence();
+    if (tile + nwaves < ntiles) {                               // prefetch the next tile under this one's math
+      const size_t nt = (size_t)(tile + nwaves);
+      gload_lin<NE>(xr, X + nt * I, lane, I);
+      gload_lin<NE>(gr, gact + nt * ld_g, lane, I);
+      gload_lin<NE>(dr, dg + nt * I, lane, I);
+    }
+    // ---- recompute U1, H1 [s][f]
+    f32x4 U[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) U[i] = mfma3(xfrag_nat(xb, i, c, g), FW1, zero4);
+    Frag UF[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+    f32x4 H1[NT];
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3(ldA(mi, ks), UF[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s = 16 * mi + 4 * g + r;
+        H1[mi][r] = s < S ? fmaxf(acc[r] + bias1, 0.f) : 0.f;
+      }
+    }
+    // ---- dZ2 [s][f'] in C layout from the staged tile (pads are zero)
+    f32x4 dZ[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = db[(16 * i + 4 * g + r) * XS + c];
+        dZ[i][r] = v;
+        db2acc += v;
+      }
+    Frag DZF[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) DZF[ks] = frag_of(dZ[2 * ks], (2 * ks + 1 < NT) ? dZ[2 * ks + 1] : zero4);
+    // ---- dU2 [s'][f'] = A^T dZ2 ; dW2 += H1^T dU2
+    f32x4 dU[NT];
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3(ldT(mi, ks), DZF[ks], acc);
+      dU[mi] = acc;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 h1 = (2 * ks + 1 < NT) ? H1[2 * ks + 1] : zero4;
+      const f32x4 d1 = (2 * ks + 1 < NT) ? dU[2 * ks + 1] : zero4;
+      dW2acc = mfma3(frag_of(H1[2 * ks], h1), frag_of(dU[2 * ks], d1), dW2acc);
+    }
+    // ---- dU2t [f'][s'] = dZ2^T A ; dH1 [s'][f] = dU2 W2^T ; dZ1 = dH1 * (H1 > 0)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3(DZF[ks], ldT(n, ks), acc);
+      const f32x4 dh = mfma3(frag_of(acc, zero4), FW2T, zero4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = H1[n][r] > 0.f ? dh[r] : 0.f;
+        dZ[n][r] = v;
+        db1acc += v;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) DZF[ks] = frag_of(dZ[2 * ks], (2 * ks + 1 < NT) ? dZ[2 * ks + 1] : zero4);
+    // ---- dU1 = A^T dZ1 ; dW1 += X^T dU1 (X read from the staged tile in C layout [s'][f])
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3(ldT(mi, ks), DZF[ks], acc);
+      dU[mi] = acc;
+    }
+    f32x4 XC[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) XC[i][r] = xb[(16 * i + 4 * g + r) * XS + c];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4 x1 = (2 * ks + 1 < NT) ? XC[2 * ks + 1] : zero4;
+      const f32x4 d1 = (2 * ks + 1 < NT) ? dU[2 * ks + 1] : zero4;
+      dW1acc = mfma3(frag_of(XC[2 * ks], x1), frag_of(dU[2 * ks], d1), dW1acc);
+    }
+  }
+
+  // ---- per-block reduction of the 4 waves, one partial row per block (deterministic order)
+  float* mine = red + wave * PART;
+  for (int i = lane; i < PART; i += 64) mine[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    mine[(4 * g + r) * FP + c] = dW1acc[r] * s_out;
+    mine[FP * FP + (4 * g + r) * FP + c] = dW2acc[r] * s_out;
+  }
+  // column sums: lanes c, c+16, c+32, c+48 hold partial sums of column c
+  db1acc += __shfl_xor(db1acc, 16, 64);
+  db1acc += __shfl_xor(db1acc, 32, 64);
+  db2acc += __shfl_xor(db2acc, 16, 64);
+  db2acc += __shfl_xor(db2acc, 32, 64);
+  if (g == 0) {
+    mine[2 * FP * FP + c] = db1acc * s_out;
+    mine[2 * FP * FP + FP + c] = db2acc * s_out;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PART; i += blockDim.x)
+    partial[(size_t)blockIdx.x * PART + i] = red[i] + red[PART + i] + red[2 * PART + i] + red[3 * PART + i];
+}
+
+int grid_x(int ntiles) {
+  int g = cdiv_i(ntiles, 4);
+  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+}
+
+}  // namespace
+
+size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)grid_x(ntiles) * PART; }
+int gcnx_bwd_grid(int ntiles) { return grid_x(ntiles); }
+
+int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+                     const float* W2, const float* b2, float* g, int ldg, hipStream_t st) {
+  const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
+  const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
+  const dim3 grid(grid_x(ntiles));
+#define FWD_CASE(NT)                                                                                              \
+  PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                             \
+              hipLaunchKernelGGL(gcnx_fwd_kernel<NT>, grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, b2, g, ldg))
+  switch ((S + 15) / 16) {
+    case 1: FWD_CASE(1); break;
+    case 2: FWD_CASE(2); break;
+    case 3: FWD_CASE(3); break;
+    case 4: FWD_CASE(4); break;
+    default: return WGNN_ERR_UNSUPPORTED;
+  }
+#undef FWD_CASE
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+                     const float* W2, const float* g, int ldg, const float* dg, const float* scales, float* partial,
+                     hipStream_t st) {
+  const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
+  const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
+  const dim3 grid(grid_x(ntiles));
+#define BWD_CASE(NT)                                                                                               \
+  PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                              \
+              hipLaunchKernelGGL(gcnx_bwd_kernel<NT>, grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, g, ldg, dg, \
+                                 scales, partial))
+  switch ((S + 15) / 16) {
+    case 1: BWD_CASE(1); break;
+    case 2: BWD_CASE(2); break;
+    case 3: BWD_CASE(3); break;
+    case 4: BWD_CASE(4); break;
+    default: return WGNN_ERR_UNSUPPORTED;
+  }
+#undef BWD_CASE
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
