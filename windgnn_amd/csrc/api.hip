@@ -80,11 +80,11 @@ int check_dims(const wgnn_dims* d) {
   if ((int64_t)d->B * d->T > (1 << 30)) return WGNN_ERR_SHAPE;
   if (d->adj_format != WGNN_ADJ_DENSE) return WGNN_ERR_UNSUPPORTED;
   if (d->S > 64) return WGNN_ERR_UNSUPPORTED;       // dense LDS-resident adjacency path
-  if (!gru_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
+  if (d->math == WGNN_MATH_F32 && !gru_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
   if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3) return WGNN_ERR_DTYPE;
   if (d->math == WGNN_MATH_F16X3) {
     // split-fp16 GEMM tiles cover all of N in one workgroup: 3H <= 320 (TN) and S*13 <= 448
-    if (3 * d->H > 320 || d->S * d->F > 448) return WGNN_ERR_UNSUPPORTED;
+    if (3 * d->H > 320 || d->S * d->F > 448 || !grux_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
   }
   return WGNN_OK;
 }
@@ -151,7 +151,7 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   if (rc != WGNN_OK) return rc;
   if (x3) {
     rc = launch_xgemm_nt(g, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI, (int)L.G3, (int)L.G3,
-                         p->b_ih, nullptr, st);
+                         p->b_ih, nullptr, nullptr, st);
   } else {
     GemmArgs ga = {};
     ga.A = g; ga.lda = (int)L.Ip; ga.a_kcontig = 1;
@@ -161,6 +161,7 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     rc = launch_gemm_f32(ga, st);
   }
   if (rc != WGNN_OK) return rc;
+  if (x3) return launch_grux_fwd(d->B, d->T, d->H, GI, p->w_hh, p->b_hh, Y, gates, st);
   return launch_gru_fwd(d->B, d->T, d->H, GI, p->w_hh, p->b_hh, Y, gates, st);
 }
 
@@ -191,19 +192,22 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);
     if (rc != WGNN_OK) return rc;
   }
-  rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
+  // f16x3: dGI/dGH (and everything derived from them, dg included) stay in units scaled by scales[0];
+  // only the final gradients are multiplied by scales[1].
+  if (x3) rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGI, dGH, (int)L.Gp, st);
+  else rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
   if (rc != WGNN_OK) return rc;
 
   if (x3) {
     // dW_hh = dGH^T [Hprev | 1]
     rc = launch_xgemm_tn(dGH, (int)L.Gp, (int)L.G3, Y, (int)L.H, (int)L.H, (int)L.H, d->T, (int)L.BT, L.sk_hh, part,
-                         (int)L.G3, (int)L.H + 1, scales, st);
+                         (int)L.G3, (int)L.H + 1, nullptr, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales, st);
     if (rc != WGNN_OK) return rc;
     // dW_ih = dGI^T [g | 1]
     rc = launch_xgemm_tn(dGI, (int)L.Gp, (int)L.G3, gact, (int)L.Ip, (int)L.I, (int)L.I, 0, (int)L.BT, L.sk_ih, part,
-                         (int)L.G3, (int)L.I + 1, scales, st);
+                         (int)L.G3, (int)L.I + 1, nullptr, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales, st);
     if (rc != WGNN_OK) return rc;
@@ -211,7 +215,7 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     rc = launch_split_weight(p->w_ih, (int)L.G3, (int)L.I, 1, ws + L.ws_planes_b, L.np_i, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_xgemm_nt(dGI, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I, (int)L.I,
-                         nullptr, scales, st);
+                         nullptr, nullptr, nullptr, st);
     if (rc != WGNN_OK) return rc;
   } else {
     // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
@@ -245,7 +249,7 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
 
   if (x3) {
     rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
-                          scales, ws + L.ws_gcnpart, st);
+                          scales, /*scale_in=*/0, ws + L.ws_gcnpart, st);
     if (rc != WGNN_OK) return rc;
     return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT), g->conv1_weight, g->conv1_bias,
                                      g->conv2_weight, g->conv2_bias, st);

@@ -70,11 +70,18 @@ int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* 
 int launch_split_weight(const float* W, int R, int C, int transpose, void* planes, int Rp, int Cp, hipStream_t st);
 int launch_amax_scale(const float* x, int64_t n, float* scales, float* part, hipStream_t st);
 int xgemm_nt_np(int N);   // padded row count of the B planes for N output columns, -1 if unsupported
+// s_in: A is multiplied by s_in[0] while splitting; s_out: C is multiplied by s_out[1] (both nullable)
 int launch_xgemm_nt(const float* A, int lda, int M, int Kp, const void* Bplanes, int Np, float* C, int ldc, int N,
-                    const float* bias, const float* scales, hipStream_t st);
+                    const float* bias, const float* s_in, const float* s_out, hipStream_t st);
 int launch_xgemm_tn(const float* A, int lda, int mcols, const float* B, int ldb, int ncols_b, int ones_col,
-                    int shift_T, int K, int splitk, float* partial, int Mout, int Nout, const float* scales,
+                    int shift_T, int K, int splitk, float* partial, int Mout, int Nout, const float* s_in,
                     hipStream_t st);
+// split-fp16 GRU recurrences with register-resident weights (grux.hip)
+bool grux_shape_supported(int H);
+int launch_grux_fwd(int B, int T, int H, const float* GI, const float* Whh, const float* bhh, float* Y, float* gates,
+                    hipStream_t st);
+int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
+                    const float* scales, float* dGI, float* dGH, int ldd, hipStream_t st);
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,
                     const float* b1, const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
@@ -91,8 +98,8 @@ int gcnx_bwd_grid(int ntiles);
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* g, int ldg, const float* dg, const float* scales, float* partial,
-                     hipStream_t st);
+                     const float* W2, const float* g, int ldg, const float* dg, const float* scales, int scale_in,
+                     float* partial, hipStream_t st);
 int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W,
                     const float* b, float* out, hipStream_t st);
 size_t gcn1_bwd_partial_floats(int ntiles);

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const float* __restrict__ gact, int ld_g,
                                                        const float* __restrict__ dg, const float* __restrict__ scales,
-                                                       float* __restrict__ partial) {
+                                                       int scale_in, float* __restrict__ partial) {
   constexpr int KS = (NT + 1) / 2;
   constexpr int NF = NT * KS;
   constexpr int SP = 16 * NT;
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
     FW2T = split_vals(x2);
   }
   const float bias1 = c < F13 ? b1[c] : 0.f;         // H1 is [s][f] here: bias per column
-  const float s_in = scales ? scales[0] : 1.f, s_out = scales ? scales[1] : 1.f;
+  const float s_in = (scales && scale_in) ? scales[0] : 1.f, s_out = scales ? scales[1] : 1.f;
   LinMap<NE> map;
   map.init(lane, I);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -463,15 +463,15 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const fl
 }
 
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* g, int ldg, const float* dg, const float* scales, float* partial,
-                     hipStream_t st) {
+                     const float* W2, const float* g, int ldg, const float* dg, const float* scales, int scale_in,
+                     float* partial, hipStream_t st) {
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
   const dim3 grid(grid_x(ntiles));
 #define BWD_CASE(NT)                                                                                               \
   PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                              \
               hipLaunchKernelGGL(gcnx_bwd_kernel<NT>, grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, g, ldg, dg, \
-                                 scales, partial))
+                                 scales, scale_in, partial))
   switch ((S + 15) / 16) {
     case 1: BWD_CASE(1); break;
     case 2: BWD_CASE(2); break;

@@ -1,0 +1,335 @@
+// GRU recurrence, split-fp16 ("f16x3") MFMA, weights resident in REGISTERS.
+//
+// Reference: nn.GRU (1 layer, batch_first, h0 = 0, gates r,z,n) at
+// src/step6_gcn_gru_combined_model.py:11,23 and its BPTT (src/main.py:79).
+//
+// One workgroup = 16 windows for all T steps, 8 waves; wave w owns hidden units [16w, 16w+16) for
+// all three gates, so the gate math is lane-local in the 16x16 C layout.  Each wave keeps its slice
+// of W_hh (forward: B operand [k = h index][n = gate unit]; backward: W_hh^T slice
+// [k = gate row][n = hidden unit]) as fp16 hi/lo MFMA fragments in VGPRs for the whole launch
+// (96 / 80 registers at H = 102); LDS only carries the 16 x H state (h, or dgh in the backward)
+// between waves, stored as fp16 hi/lo rows padded to a conflict-free stride.
+// Backward values (dY ~ 1e-9) are multiplied by the power of two scales[0] on load and written
+// SCALED to dGI/dGH; the weight-gradient GEMMs un-scale in their epilogues.
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int MB = 16;
+constexpr int NTHREADS = 512;
+
+struct Frag { h8 hi, lo; };
+
+__device__ __forceinline__ f32x4 mfma_x(h8 a, h8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
+  c = mfma_x(a.lo, b.hi, c);
+  c = mfma_x(a.hi, b.lo, c);
+  c = mfma_x(a.hi, b.hi, c);
+  return c;
+}
+__device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
+  Frag f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 h = (_Float16)x[j];
+    f.hi[j] = h;
+    f.lo[j] = (_Float16)(x[j] - (float)h);
+  }
+  return f;
+}
+__device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, float v) {
+  const _Float16 h = (_Float16)v;
+  hi[idx] = h;
+  lo[idx] = (_Float16)(v - (float)h);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int KS>   // K steps of 32 over the hidden index: KS = ceil(H/32)
+__global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const float* __restrict__ GI,
+                                                            const float* __restrict__ Whh,
+                                                            const float* __restrict__ bhh, float* __restrict__ Y,
+                                                            float* __restrict__ gates) {
+  constexpr int HS = 32 * KS + 8;                  // row stride in halfs: 16-B aligned, conflict-free reads
+  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * MB * HS];
+  _Float16* hhi = hbuf;
+  _Float16* hlo = hbuf + MB * HS;
+  for (int i = threadIdx.x; i < 2 * MB * HS; i += NTHREADS) hbuf[i] = (_Float16)0.f;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int j = 16 * wave + c;
+  const bool active = 16 * wave < H;               // wave-uniform
+  const bool jv = j < H;
+  const int jc = jv ? j : H - 1;
+  const int b0 = blockIdx.x * MB;
+  const int G3 = 3 * H;
+
+  Frag WB[3][KS];                                  // B operand: W_hh[(gate*H + j)][k], k = 32ks + 8g + jj
+#pragma unroll
+  for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int k = 32 * ks + 8 * g + jj;
+        x[jj] = (jv && k < H) ? Whh[(size_t)(gate * H + j) * H + k] : 0.f;
+      }
+      WB[gate][ks] = split_vals(x);
+    }
+  const float bh_r = bhh[jc], bh_z = bhh[H + jc], bh_n = bhh[2 * H + jc];
+
+  // per-row base offsets (clamped so every load is unconditional)
+  size_t rowoff[4];
+  bool rowok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * g + r;
+    rowok[r] = jv && b < B;
+    rowoff[r] = (size_t)(b < B ? b : B - 1) * T;
+  }
+  float gi[3][4], gin[3][4];
+  auto load_gi = [&](int t, float (&dst)[3][4]) {
+    const int tc = t < T ? t : T - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row = GI + (rowoff[r] + tc) * G3 + jc;
+      dst[0][r] = row[0];
+      dst[1][r] = row[H];
+      dst[2][r] = row[2 * H];
+    }
+  };
+  load_gi(0, gi);
+  float hold[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    load_gi(t + 1, gin);                           // prefetch under this step's MFMAs
+    float hnew[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      f32x4 ar, az, an;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ar[r] = gi[0][r] + bh_r;
+        az[r] = gi[1][r] + bh_z;
+        an[r] = bh_n;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        Frag a;
+        a.hi = *(const h8*)(hhi + c * HS + 32 * ks + 8 * g);
+        a.lo = *(const h8*)(hlo + c * HS + 32 * ks + 8 * g);
+        ar = mfma3(a, WB[0][ks], ar);
+        az = mfma3(a, WB[1][ks], az);
+        an = mfma3(a, WB[2][ks], an);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float rg = sigmoidf_(ar[r]);
+        const float zg = sigmoidf_(az[r]);
+        const float ng = tanhf_(gi[2][r] + rg * an[r]);
+        hnew[r] = (1.f - zg) * ng + zg * hold[r];
+        if (rowok[r]) {
+          const size_t bt = rowoff[r] + t;
+          Y[bt * H + j] = hnew[r];
+          if (gates) {
+            float* gp = gates + bt * 4 * H + j;
+            gp[0] = rg;
+            gp[H] = zg;
+            gp[2 * H] = ng;
+            gp[3 * H] = an[r];
+          }
+        }
+        hold[r] = hnew[r];
+      }
+    }
+    __syncthreads();                               // every wave has read h_{t-1}
+    if (active && jv) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) put_split(hhi, hlo, (4 * g + r) * HS + j, hnew[r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gi[q][r] = gin[q][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BPTT; per step (t descending), dh = s*dY_t + dh_next (everything in units scaled by s = scales[0]):
+//   dn = dh (1-z), dz = dh (hprev - n), dnt = dn (1-n^2), dr = dnt gh_n,
+//   dar = dr r (1-r), daz = dz z (1-z);  dgi = [dar, daz, dnt], dgh = [dar, daz, dnt r]
+//   dh_next = dh z + dgh W_hh
+template <int KS3>   // K steps of 32 over the 3H gate rows
+__global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
+                                                            const float* __restrict__ Y, const float* __restrict__ dY,
+                                                            const float* __restrict__ gates,
+                                                            const float* __restrict__ scales, float* __restrict__ dGI,
+                                                            float* __restrict__ dGH, int ldd) {
+  constexpr int DS = 32 * KS3 + 8;
+  __shared__ __attribute__((aligned(16))) _Float16 dbuf[2 * MB * DS];
+  _Float16* dhi = dbuf;
+  _Float16* dlo = dbuf + MB * DS;
+  for (int i = threadIdx.x; i < 2 * MB * DS; i += NTHREADS) dbuf[i] = (_Float16)0.f;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int j = 16 * wave + c;
+  const bool active = 16 * wave < H;
+  const bool jv = j < H;
+  const int jc = jv ? j : H - 1;
+  const int b0 = blockIdx.x * MB;
+  const int G3 = 3 * H;
+  const float s_in = scales ? scales[0] : 1.f;
+
+  Frag WT[KS3];                                    // B operand: W_hh[k][j], k = 32ks + 8g + jj (gate row)
+#pragma unroll
+  for (int ks = 0; ks < KS3; ++ks) {
+    float x[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int k = 32 * ks + 8 * g + jj;
+      x[jj] = (jv && k < G3) ? Whh[(size_t)k * H + j] : 0.f;
+    }
+    WT[ks] = split_vals(x);
+  }
+  {  // zero the K-padding columns [3H, ldd) of this workgroup's dGI/dGH rows
+    const int npad = ldd - G3;
+    const int nrows = min(MB, B - b0) * T;
+    for (int i = threadIdx.x; i < nrows * npad; i += NTHREADS) {
+      const size_t o = ((size_t)b0 * T + i / npad) * ldd + G3 + i % npad;
+      dGI[o] = 0.f;
+      dGH[o] = 0.f;
+    }
+  }
+  size_t rowoff[4];
+  bool rowok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * g + r;
+    rowok[r] = jv && b < B;
+    rowoff[r] = (size_t)(b < B ? b : B - 1) * T;
+  }
+  struct StepIn { float dy[4], r[4], z[4], n[4], ghn[4], hp[4]; };
+  auto load_step = [&](int t, StepIn& s) {
+    const int tc = t > 0 ? t : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t bt = rowoff[r] + tc;
+      const float* gp = gates + bt * 4 * H + jc;
+      s.dy[r] = dY[bt * H + jc];
+      s.r[r] = gp[0];
+      s.z[r] = gp[H];
+      s.n[r] = gp[2 * H];
+      s.ghn[r] = gp[3 * H];
+      const float hp = Y[(bt - (tc > 0 ? 1 : 0)) * H + jc];
+      s.hp[r] = tc > 0 ? hp : 0.f;
+    }
+  };
+  StepIn cur, nxt;
+  load_step(T - 1, cur);
+  f32x4 dhn = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int t = T - 1; t >= 0; --t) {
+    load_step(t - 1, nxt);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * g + r;
+        const float dh = rowok[r] ? cur.dy[r] * s_in + dhn[r] : 0.f;
+        const float rg = cur.r[r], zg = cur.z[r], ng = cur.n[r];
+        const float dn = dh * (1.f - zg);
+        const float dz = dh * (cur.hp[r] - ng);
+        const float dnt = dn * (1.f - ng * ng);
+        const float dr = dnt * cur.ghn[r];
+        const float dar = dr * rg * (1.f - rg);
+        const float daz = dz * zg * (1.f - zg);
+        const float dnr = dnt * rg;
+        acc[r] = dh * zg;
+        if (jv) {
+          put_split(dhi, dlo, m * DS + j, dar);
+          put_split(dhi, dlo, m * DS + H + j, daz);
+          put_split(dhi, dlo, m * DS + 2 * H + j, dnr);
+        }
+        if (rowok[r]) {
+          const size_t bt = rowoff[r] + t;
+          float* gi = dGI + bt * ldd + j;
+          float* gh = dGH + bt * ldd + j;
+          gi[0] = dar; gi[H] = daz; gi[2 * H] = dnt;
+          gh[0] = dar; gh[H] = daz; gh[2 * H] = dnr;
+        }
+      }
+    }
+    __syncthreads();
+    if (active && t > 0) {
+#pragma unroll
+      for (int ks = 0; ks < KS3; ++ks) {
+        Frag a;
+        a.hi = *(const h8*)(dhi + c * DS + 32 * ks + 8 * g);
+        a.lo = *(const h8*)(dlo + c * DS + 32 * ks + 8 * g);
+        acc = mfma3(a, WT[ks], acc);
+      }
+    }
+    dhn = acc;
+    __syncthreads();
+    cur = nxt;
+  }
+}
+
+}  // namespace
+
+bool grux_shape_supported(int H) { return H >= 1 && H <= 128; }
+
+int launch_grux_fwd(int B, int T, int H, const float* GI, const float* Whh, const float* bhh, float* Y, float* gates,
+                    hipStream_t st) {
+  const double bt = (double)B * T;
+  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0));
+  const dim3 grid(cdiv_i(B, MB));
+#define FCASE(K)                                                                                                   \
+  PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                               \
+              hipLaunchKernelGGL(grux_fwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, GI, Whh, bhh, Y, gates))
+  switch (cdiv_i(H, 32)) {
+    case 1: FCASE(1); break;
+    case 2: FCASE(2); break;
+    case 3: FCASE(3); break;
+    case 4: FCASE(4); break;
+    default: return WGNN_ERR_UNSUPPORTED;
+  }
+#undef FCASE
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
+                    const float* scales, float* dGI, float* dGH, int ldd, hipStream_t st) {
+  const double bt = (double)B * T;
+  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (4 * H + 2 * H + 6 * H);
+  const dim3 grid(cdiv_i(B, MB));
+#define BCASE(K)                                                                                                   \
+  PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                               \
+              hipLaunchKernelGGL(grux_bwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, gates, scales, \
+                                 dGI, dGH, ldd))
+  switch (cdiv_i(3 * H, 32)) {
+    case 1: BCASE(1); break;
+    case 2: BCASE(2); break;
+    case 3: BCASE(3); break;
+    case 4: BCASE(4); break;
+    case 5: BCASE(5); break;
+    case 6: BCASE(6); break;
+    case 7: BCASE(7); break;
+    case 8: BCASE(8); break;
+    case 9: BCASE(9); break;
+    case 10: BCASE(10); break;
+    case 11: BCASE(11); break;
+    case 12: BCASE(12); break;
+    default: return WGNN_ERR_UNSUPPORTED;
+  }
+#undef BCASE
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}

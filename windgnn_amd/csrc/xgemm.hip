@@ -105,14 +105,15 @@ __global__ void __launch_bounds__(XT) xgemm_nt_kernel(const float* __restrict__ 
                                                       const _Float16* __restrict__ Bhi_g,
                                                       const _Float16* __restrict__ Blo_g, float* __restrict__ C,
                                                       int ldc, int N, const float* __restrict__ bias,
-                                                      const float* __restrict__ scales) {
+                                                      const float* __restrict__ s_in_p,
+                                                      const float* __restrict__ s_out_p) {
   (void)Blo_g;   // the lo plane follows the hi plane: Blo_g == Bhi_g + BN*Kp
   constexpr int BM = 128, BN = 64 * NT_W, STAGE = (2 * BM + 2 * BN) * 64, NB = BN / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave & 3) * 32, wn0 = (wave >> 2) * 32 * NT_W;
   const int m0 = blockIdx.x * BM;
-  const float s_in = scales ? scales[0] : 1.f, s_out = scales ? scales[1] : 1.f;
+  const float s_in = s_in_p ? s_in_p[0] : 1.f, s_out = s_out_p ? s_out_p[1] : 1.f;
 
   f32x16 acc[1][NT_W];
 #pragma unroll
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(XT) xgemm_tn_kernel(const float* __restrict__ 
                                                       const float* __restrict__ B, int ldb, int ncols_b,
                                                       int ones_col, int shift_T, int K, int kchunk,
                                                       float* __restrict__ partial, int Mout, int Nout,
-                                                      const float* __restrict__ scales) {
+                                                      const float* __restrict__ s_in_p) {
   constexpr int BM = 64 * MT_W, BN = 128 * NT_W, STAGE = (2 * BM + 2 * BN) * 64;
   constexpr int UA = (BM * 4 + XT - 1) / XT, UB = (BN * 4 + XT - 1) / XT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(XT) xgemm_tn_kernel(const float* __restrict__ 
   const int n0 = blockIdx.y * BN;   // blocks z + splitk*y: same z => ids differ by a multiple of splitk => one XCD
   const int z = blockIdx.x;
   const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
-  const float s_in = scales ? scales[0] : 1.f;
+  const float s_in = s_in_p ? s_in_p[0] : 1.f;
 
   f32x16 acc[MT_W][NT_W];
 #pragma unroll
@@ -362,7 +363,7 @@ int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=
 
 // C[M][N] = s_out * (s_in*A) B^T + bias; B planes [Np][Kp] with Np = 320 or 448.
 int launch_xgemm_nt(const float* A, int lda, int M, int Kp, const void* Bplanes, int Np, float* C, int ldc, int N,
-                    const float* bias, const float* scales, hipStream_t st) {
+                    const float* bias, const float* s_in, const float* s_out, hipStream_t st) {
   const _Float16* bhi = (const _Float16*)Bplanes;
   const _Float16* blo = bhi + (size_t)Np * Kp;
   const dim3 grid(cdiv_i(M, 128));
@@ -376,7 +377,7 @@ int launch_xgemm_nt(const float* A, int lda, int M, int Kp, const void* Bplanes,
       return WGNN_ERR_HIP;                                                                                        \
     PROF_LAUNCH("xgemm_nt_kernel<" #NTW ">", fl, by, st,                                                          \
                 hipLaunchKernelGGL(xgemm_nt_kernel<NTW>, grid, dim3(XT), smem, st, A, lda, M, Kp, bhi, blo, C, ldc, \
-                                   N, bias, scales));                                                             \
+                                   N, bias, s_in, s_out));                                                             \
   }
   switch (Np) {
     case 64: NT_CASE(1) break;
@@ -397,7 +398,7 @@ int xgemm_nt_np(int N) { int np = cdiv_i(N, 64) * 64; return np <= 448 ? np : -1
 
 // partial[z][Mout][Nout]; M (= A columns) <= 320.
 int launch_xgemm_tn(const float* A, int lda, int mcols, const float* B, int ldb, int ncols_b, int ones_col,
-                    int shift_T, int K, int splitk, float* partial, int Mout, int Nout, const float* scales,
+                    int shift_T, int K, int splitk, float* partial, int Mout, int Nout, const float* s_in,
                     hipStream_t st) {
   const int kchunk = cdiv_i(cdiv_i(K, splitk), 32) * 32;
   const double fl = 2.0 * Mout * (double)Nout * K;
@@ -411,7 +412,7 @@ int launch_xgemm_tn(const float* A, int lda, int mcols, const float* B, int ldb,
     const dim3 grid(splitk, cdiv_i(Nout, 128 * NTW));                                                              \
     PROF_LAUNCH("xgemm_tn_kernel<" #MTW "," #NTW ">", fl, by, st,                                                  \
                 hipLaunchKernelGGL((xgemm_tn_kernel<MTW, NTW>), grid, dim3(XT), smem, st, A, lda, mcols, B, ldb,    \
-                                   ncols_b, ones_col, shift_T, K, kchunk, partial, Mout, Nout, scales));           \
+                                   ncols_b, ones_col, shift_T, K, kchunk, partial, Mout, Nout, s_in));           \
   }
   const int mt = cdiv_i(Mout, 64);
   if (mt < 1 || mt > 5) return WGNN_ERR_UNSUPPORTED;
