@@ -23,8 +23,7 @@ S, T, F, H = 34, 24, 13, 102
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
 # which roofline bounds each kernel (DESIGN.md "Kernels")
-BOUND = {"gemm_f32_kernel": "mfma", "gcn_fwd_kernel<2>": "mfma", "gcn_bwd_kernel<2>": "mfma",
-         "gru_fwd_kernel": "mfma", "gru_bwd_kernel": "mfma"}
+BOUND_HBM_PREFIXES = ("mse_", "adam_", "amax_", "splitk_reduce", "split_weight", "gcn_partial")
 
 
 def adjacency_34():
@@ -87,7 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU (weak scaling)")
-    ap.add_argument("--math", default="f32", choices=["f32", "f16x3"])
+    ap.add_argument("--math", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -148,7 +147,7 @@ def main():
                     "ms_per_step": round(r["ms"] / args.steps, 4)} for r in recs]
         d = recs[0]
         avg_s = d["ms"] / d["launches"] * 1e-3
-        bound = BOUND.get(d["name"], "hbm")
+        bound = "hbm" if d["name"].startswith(BOUND_HBM_PREFIXES) else "mfma"
         if bound == "mfma":
             ach = d["flops"] / d["launches"] / avg_s / 1e12
             peak = MFMA_PEAK_TFLOPS[args.math]

@@ -189,7 +189,7 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   const bool x3 = d->math == WGNN_MATH_F16X3;
 
   if (x3) {
-    rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);
+    rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
     if (rc != WGNN_OK) return rc;
   }
   // f16x3: dGI/dGH (and everything derived from them, dg included) stay in units scaled by scales[0];

@@ -35,6 +35,20 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f);
 }
 
+// Opt a kernel into > 64 KB of dynamic LDS once per device (hipFuncSetAttribute takes a global lock
+// and is far too slow to repeat on every launch).
+#include <atomic>
+static inline int ensure_dyn_smem(const void* fn, size_t bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return WGNN_ERR_HIP;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return WGNN_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return WGNN_ERR_HIP;
+  done.fetch_or(bit, std::memory_order_release);
+  return WGNN_OK;
+}
+
 // ---- optional per-kernel timing (hipEvents on the launch stream); off by default ----------------
 // PROF_LAUNCH(name, flops, bytes, st, launch) wraps one kernel launch; algorithmic flops/bytes are
 // what bench.py's roofline uses.  Enabled only through wgnn_profile_enable().

@@ -237,9 +237,10 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, const float* Whh, const
                    hipStream_t st) {
   GruGeom G(H);
   size_t smem = G.fwd_bytes();
-  if (hipFuncSetAttribute((const void*)gru_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
-      hipSuccess)
-    return WGNN_ERR_HIP;
+  static std::atomic<unsigned long long> done{0};   // smem depends on H: re-arm if it grows
+  static std::atomic<size_t> armed{0};
+  if (smem > armed.load()) { done.store(0); armed.store(smem); }
+  if (ensure_dyn_smem((const void*)gru_fwd_kernel, armed.load(), done) != WGNN_OK) return WGNN_ERR_HIP;
   const double bt = (double)B * T;
   PROF_LAUNCH("gru_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0)), st,
               hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, GI, Whh, bhh,
@@ -252,9 +253,10 @@ int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const 
                    float* dGI, float* dGH, int ldd, hipStream_t st) {
   GruGeom G(H);
   size_t smem = G.bwd_bytes();
-  if (hipFuncSetAttribute((const void*)gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
-      hipSuccess)
-    return WGNN_ERR_HIP;
+  static std::atomic<unsigned long long> done{0};
+  static std::atomic<size_t> armed{0};
+  if (smem > armed.load()) { done.store(0); armed.store(smem); }
+  if (ensure_dyn_smem((const void*)gru_bwd_kernel, armed.load(), done) != WGNN_OK) return WGNN_ERR_HIP;
   const double bt = (double)B * T;
   PROF_LAUNCH("gru_bwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (4 * H + 2 * H + 6 * H), st,
               hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, Whh, Y, dY,

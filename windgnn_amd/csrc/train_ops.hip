@@ -6,14 +6,25 @@
 
 namespace {
 
-constexpr int MSE_BLOCKS = 256;
+constexpr int MSE_BLOCKS = 1024;   // partials fit the 4096-byte workspace the ABI asks for
 
 __global__ void __launch_bounds__(256) mse_kernel(const float* __restrict__ Y, const float* __restrict__ L,
                                                   int64_t n, float gscale, float* __restrict__ dY,
                                                   float* __restrict__ part) {
   float s = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool al = ((((uintptr_t)Y) | ((uintptr_t)L) | ((uintptr_t)dY)) & 15) == 0;
+  const int64_t n4 = al ? n / 4 : 0;
+  const f32x4* Y4 = (const f32x4*)Y;
+  const f32x4* L4 = (const f32x4*)L;
+  f32x4* D4 = (f32x4*)dY;
+  for (int64_t i = gid; i < n4; i += stride) {
+    const f32x4 d = Y4[i] - L4[i];
+    s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    if (dY) D4[i] = d * gscale;
+  }
+  for (int64_t i = 4 * n4 + gid; i < n; i += stride) {
     const float d = Y[i] - L[i];
     s += d * d;
     if (dY) dY[i] = d * gscale;

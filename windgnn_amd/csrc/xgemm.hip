@@ -311,7 +311,14 @@ __global__ void __launch_bounds__(256) amax_partial_kernel(const float* __restri
                                                            float* __restrict__ part) {
   float m = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = (((uintptr_t)x & 15) == 0) ? n / 4 : 0;
+  const f32x4* x4 = (const f32x4*)x;
+  for (int64_t i = gid; i < n4; i += stride) {
+    const f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (int64_t i = 4 * n4 + gid; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
   __shared__ float ws[4];
@@ -352,11 +359,11 @@ int launch_split_weight(const float* W, int R, int C, int transpose, void* plane
   return WGNN_OK;
 }
 
-int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=256 floats*/, hipStream_t st) {
+int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=448 floats*/, hipStream_t st) {
   PROF_LAUNCH("amax_partial_kernel", (double)n, 4.0 * n, st,
-              hipLaunchKernelGGL(amax_partial_kernel, dim3(256), dim3(256), 0, st, x, n, part));
+              hipLaunchKernelGGL(amax_partial_kernel, dim3(448), dim3(256), 0, st, x, n, part));
   WGNN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(64), 0, st, part, 256, scales);
+  hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(64), 0, st, part, 448, scales);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -372,9 +379,8 @@ int launch_xgemm_nt(const float* A, int lda, int M, int Kp, const void* Bplanes,
 #define NT_CASE(NTW)                                                                                              \
   {                                                                                                               \
     const size_t smem = 2 * (size_t)(2 * 128 + 2 * 64 * NTW) * 64;                                                \
-    if (hipFuncSetAttribute((const void*)xgemm_nt_kernel<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                            (int)smem) != hipSuccess)                                                             \
-      return WGNN_ERR_HIP;                                                                                        \
+    static std::atomic<unsigned long long> done{0};                                                               \
+    if (ensure_dyn_smem((const void*)xgemm_nt_kernel<NTW>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;           \
     PROF_LAUNCH("xgemm_nt_kernel<" #NTW ">", fl, by, st,                                                          \
                 hipLaunchKernelGGL(xgemm_nt_kernel<NTW>, grid, dim3(XT), smem, st, A, lda, M, Kp, bhi, blo, C, ldc, \
                                    N, bias, s_in, s_out));                                                             \
@@ -406,9 +412,8 @@ int launch_xgemm_tn(const float* A, int lda, int mcols, const float* B, int ldb,
 #define TN_CASE(MTW, NTW)                                                                                          \
   {                                                                                                                \
     const size_t smem = 2 * (size_t)(2 * 64 * MTW + 2 * 128 * NTW) * 64;                                           \
-    if (hipFuncSetAttribute((const void*)xgemm_tn_kernel<MTW, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                            (int)smem) != hipSuccess)                                                              \
-      return WGNN_ERR_HIP;                                                                                         \
+    static std::atomic<unsigned long long> done{0};                                                                \
+    if (ensure_dyn_smem((const void*)xgemm_tn_kernel<MTW, NTW>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;       \
     const dim3 grid(splitk, cdiv_i(Nout, 128 * NTW));                                                              \
     PROF_LAUNCH("xgemm_tn_kernel<" #MTW "," #NTW ">", fl, by, st,                                                  \
                 hipLaunchKernelGGL((xgemm_tn_kernel<MTW, NTW>), grid, dim3(XT), smem, st, A, lda, mcols, B, ldb,    \
