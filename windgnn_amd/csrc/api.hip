@@ -41,7 +41,7 @@ Layout make_layout(const wgnn_dims* d) {
   const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : 0;   // 2 planes of halfs = that many floats
   const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : 0;
   size_t o = 0;
-  L.ws_GI = o; o += al(L.BT * L.G3);
+  L.ws_GI = o; o += al(L.BT * L.Gp);   // rows padded to 128-B multiples
   L.ws_g = o; o += al(L.BT * L.Ip);
   L.ws_planes_f = o; o += al(planes_f);
   L.fwd_floats = o;
@@ -150,19 +150,19 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
                          (int)L.Ip, st);
   if (rc != WGNN_OK) return rc;
   if (x3) {
-    rc = launch_xgemm_nt(g, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI, (int)L.G3, (int)L.G3,
+    rc = launch_xgemm_nt(g, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI, (int)L.Gp, (int)L.G3,
                          p->b_ih, nullptr, nullptr, st);
   } else {
     GemmArgs ga = {};
     ga.A = g; ga.lda = (int)L.Ip; ga.a_kcontig = 1;
     ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
-    ga.C = GI; ga.ldc = (int)L.G3; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
+    ga.C = GI; ga.ldc = (int)L.Gp; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
     ga.bias = p->b_ih; ga.splitk = 1;
     rc = launch_gemm_f32(ga, st);
   }
   if (rc != WGNN_OK) return rc;
-  if (x3) return launch_grux_fwd(d->B, d->T, d->H, GI, p->w_hh, p->b_hh, Y, gates, st);
-  return launch_gru_fwd(d->B, d->T, d->H, GI, p->w_hh, p->b_hh, Y, gates, st);
+  if (x3) return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, st);
+  return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, st);
 }
 
 int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,

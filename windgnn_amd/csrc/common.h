@@ -30,6 +30,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Hardware-transcendental forms (v_exp_f32 + v_rcp_f32, ~1 ulp each): 4 instructions instead of the
+// ~30 of the IEEE-exact expf + division.  |error| < 3e-7, far inside the path's 1e-4 budget; the
+// limits are exact (exp2 -> 0 or inf, rcp(inf) = 0).
+__device__ __forceinline__ float sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * x) + 1.0f);
+}
 __device__ __forceinline__ float tanhf_(float x) {
   // 1 - 2/(e^{2x}+1): exact limits at +-inf, abs error ~1e-7
   return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f);
@@ -92,8 +101,8 @@ int launch_xgemm_tn(const float* A, int lda, int mcols, const float* B, int ldb,
                     hipStream_t st);
 // split-fp16 GRU recurrences with register-resident weights (grux.hip)
 bool grux_shape_supported(int H);
-int launch_grux_fwd(int B, int T, int H, const float* GI, const float* Whh, const float* bhh, float* Y, float* gates,
-                    hipStream_t st);
+int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                    float* gates, hipStream_t st);
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
                     const float* scales, float* dGI, float* dGH, int ldd, hipStream_t st);
 
@@ -121,7 +130,7 @@ int launch_gcn1_bwd(int ntiles, int S, const float* A, const float* X, const flo
                     const float* out, const float* dout, float* dW, float* db, float* dX,
                     float* partial, hipStream_t st);
 
-int launch_gru_fwd(int B, int T, int H, const float* GI, const float* Whh, const float* bhh,
+int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh,
                    float* Y, float* gates /*nullable [B*T][4H]*/, hipStream_t st);
 int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY,
                    const float* gates, float* dGI, float* dGH, int ldd, hipStream_t st);

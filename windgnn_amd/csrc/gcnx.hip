@@ -165,14 +165,16 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
 
   float xr[NE];
-  if (wave_id < ntiles) gload_lin<NE>(xr, X + (size_t)wave_id * I, lane, I);
-  for (int tile = wave_id; tile < ntiles; tile += nwaves) {
-    wave_lds_fence();                                 // previous tile's LDS reads are done
+  if (wave_id < ntiles) {
+    gload_lin<NE>(xr, X + (size_t)wave_id * I, lane, I);
 #pragma unroll
     for (int k = 0; k < NE; ++k)
       if (lane + 64 * k < I) xb[map.off[k]] = xr[k];
-    wave_lds_fence();
-    if (tile + nwaves < ntiles) gload_lin<NE>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch
+  }
+  for (int tile = wave_id; tile < ntiles; tile += nwaves) {
+    wave_lds_fence();                                 // this tile's X is staged
+    const bool more = tile + nwaves < ntiles;
+    if (more) gload_lin<NE>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch the next tile
 
     f32x4 U[NT];
 #pragma unroll
@@ -204,6 +206,13 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
       *(f32x4*)(ob + (16 * n + c) * XS + 4 * g) = v;           // g^T[f' = 4g..4g+3][s] -> staged [s][f']
     }
     wave_lds_fence();
+    // Stage the NEXT tile's X now (xb was last read by the U1 products above), i.e. wait for the
+    // prefetch BEFORE this tile's output stores are issued, so the wait never covers the stores.
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < NE; ++k)
+        if (lane + 64 * k < I) xb[map.off[k]] = xr[k];
+    }
     float* dst = out + (size_t)tile * ld_out;
 #pragma unroll
     for (int k = 0; k < NE; ++k) {

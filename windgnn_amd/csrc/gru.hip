@@ -31,7 +31,7 @@ struct GruGeom {
   __host__ __device__ size_t bwd_bytes() const { return (size_t)(3 * H * H + WPAD + MB * DS) * 4; }
 };
 
-__global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, const float* __restrict__ GI,
+__global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, const float* __restrict__ GI, int ldgi,
                                                            const float* __restrict__ Whh,
                                                            const float* __restrict__ bhh, float* __restrict__ Y,
                                                            float* __restrict__ gates) {
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, 
     for (int r = 0; r < 4; ++r) {
       const int b = b0 + 4 * lk + r;
       const bool ok = jv && b < B && t < T;
-      const float* row = GI + ((size_t)(ok ? b : 0) * T + (ok ? t : 0)) * G3;
+      const float* row = GI + ((size_t)(ok ? b : 0) * T + (ok ? t : 0)) * ldgi;
       dst[0][r] = ok ? row[j] : 0.f;
       dst[1][r] = ok ? row[H + j] : 0.f;
       dst[2][r] = ok ? row[2 * H + j] : 0.f;
@@ -233,8 +233,8 @@ bool gru_shape_supported(int H) {
   return G.bwd_bytes() <= 160 * 1024 && G.fwd_bytes() <= 160 * 1024;
 }
 
-int launch_gru_fwd(int B, int T, int H, const float* GI, const float* Whh, const float* bhh, float* Y, float* gates,
-                   hipStream_t st) {
+int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                   float* gates, hipStream_t st) {
   GruGeom G(H);
   size_t smem = G.fwd_bytes();
   static std::atomic<unsigned long long> done{0};   // smem depends on H: re-arm if it grows
@@ -243,8 +243,8 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, const float* Whh, const
   if (ensure_dyn_smem((const void*)gru_fwd_kernel, armed.load(), done) != WGNN_OK) return WGNN_ERR_HIP;
   const double bt = (double)B * T;
   PROF_LAUNCH("gru_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0)), st,
-              hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, GI, Whh, bhh,
-                                 Y, gates));
+              hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv_i(B, MB)), dim3(NTHREADS), smem, st, B, T, H, GI, ldgi, Whh,
+                                 bhh, Y, gates));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

@@ -49,7 +49,7 @@ __device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, f
 
 // ------------------------------------------------------------------------------------------------
 template <int KS>   // K steps of 32 over the hidden index: KS = ceil(H/32)
-__global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const float* __restrict__ GI,
+__global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const float* __restrict__ GI, int ldgi,
                                                             const float* __restrict__ Whh,
                                                             const float* __restrict__ bhh, float* __restrict__ Y,
                                                             float* __restrict__ gates) {
@@ -65,7 +65,6 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   const bool jv = j < H;
   const int jc = jv ? j : H - 1;
   const int b0 = blockIdx.x * MB;
-  const int G3 = 3 * H;
 
   Frag WB[3][KS];                                  // B operand: W_hh[(gate*H + j)][k], k = 32ks + 8g + jj
 #pragma unroll
@@ -96,7 +95,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     const int tc = t < T ? t : T - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float* row = GI + (rowoff[r] + tc) * G3 + jc;
+      const float* row = GI + (rowoff[r] + tc) * ldgi + jc;
       dst[0][r] = row[0];
       dst[1][r] = row[H];
       dst[2][r] = row[2 * H];
@@ -128,9 +127,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float rg = sigmoidf_(ar[r]);
-        const float zg = sigmoidf_(az[r]);
-        const float ng = tanhf_(gi[2][r] + rg * an[r]);
+        const float rg = sigmoid_fast(ar[r]);
+        const float zg = sigmoid_fast(az[r]);
+        const float ng = tanh_fast(gi[2][r] + rg * an[r]);
         hnew[r] = (1.f - zg) * ng + zg * hold[r];
         if (rowok[r]) {
           const size_t bt = rowoff[r] + t;
@@ -285,14 +284,14 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 
 bool grux_shape_supported(int H) { return H >= 1 && H <= 128; }
 
-int launch_grux_fwd(int B, int T, int H, const float* GI, const float* Whh, const float* bhh, float* Y, float* gates,
-                    hipStream_t st) {
+int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                    float* gates, hipStream_t st) {
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0));
   const dim3 grid(cdiv_i(B, MB));
 #define FCASE(K)                                                                                                   \
   PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                               \
-              hipLaunchKernelGGL(grux_fwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, GI, Whh, bhh, Y, gates))
+              hipLaunchKernelGGL(grux_fwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, Y, gates))
   switch (cdiv_i(H, 32)) {
     case 1: FCASE(1); break;
     case 2: FCASE(2); break;

@@ -15,6 +15,8 @@
 //
 // LDS tiles are [row][32 k] fp16 (64-B rows) with the 16-B chunk index XOR-swizzled by
 // (row>>2)&3, which makes the ds_read_b128 fragment reads of v_mfma_f32_32x32x16_f16 conflict-free.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -74,7 +76,7 @@ __device__ __forceinline__ void compute_stage(const char* Ahi, const char* Alo, 
 
 template <int NB>
 __device__ __forceinline__ void nt_gload(bool arow_ok, const float* aptr, const _Float16* Bg, const int (&b_src)[NB],
-                                         int k0, f32x4& av0, f32x4& av1, u32x4 (&breg)[NB]) {
+                                         int kt_stride, int k0, f32x4& av0, f32x4& av1, u32x4 (&breg)[NB]) {
   if (arow_ok) {
     av0 = *(const f32x4*)(aptr + k0);
     av1 = *(const f32x4*)(aptr + k0 + 4);
@@ -83,7 +85,7 @@ __device__ __forceinline__ void nt_gload(bool arow_ok, const float* aptr, const 
     av1 = av0;
   }
 #pragma unroll
-  for (int it = 0; it < NB; ++it) breg[it] = *(const u32x4*)(Bg + b_src[it] + k0);
+  for (int it = 0; it < NB; ++it) breg[it] = *(const u32x4*)(Bg + b_src[it] + (size_t)(k0 >> 5) * kt_stride);
 }
 
 template <int NB>
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(XT) xgemm_nt_kernel(const float* __restrict__ 
                                                       const _Float16* __restrict__ Blo_g, float* __restrict__ C,
                                                       int ldc, int N, const float* __restrict__ bias,
                                                       const float* __restrict__ s_in_p,
-                                                      const float* __restrict__ s_out_p) {
+                                                      const float* __restrict__ s_out_p, int dbg) {
   (void)Blo_g;   // the lo plane follows the hi plane: Blo_g == Bhi_g + BN*Kp
   constexpr int BM = 128, BN = 64 * NT_W, STAGE = (2 * BM + 2 * BN) * 64, NB = BN / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,28 +133,42 @@ __global__ void __launch_bounds__(XT) xgemm_nt_kernel(const float* __restrict__ 
     const int q = tid + XT * it;
     const int plane = q / (BN * 4), rem = q - plane * (BN * 4);
     const int row = rem >> 2, c = rem & 3;
-    b_src[it] = plane * BN * Kp + row * Kp + 8 * c;          // in halfs, relative to Bhi_g (planes are adjacent)
+    b_src[it] = plane * BN * Kp + row * 32 + 8 * c;          // halfs; planes are stage-major [kt][BN][32], lo after hi
     b_dst[it] = 2 * BM * 64 + plane * BN * 64 + sw_off(row, c);
   }
   const int a_dst = sw_off(arow, akc);
-  f32x4 av0, av1;
-  u32x4 breg[NB];
-
+  // Two register staging sets: the loads of stage kt+2 are issued while stage kt computes, so each
+  // load has two full compute phases to land (the kernel was load-latency-bound with one).
+  f32x4 a0A, a1A, a0B, a1B;
+  u32x4 bA[NB], bB[NB];
   const int nk = Kp / 32;
-  nt_gload<NB>(arow_ok, aptr, Bhi_g, b_src, 0, av0, av1, breg);
-  nt_swrite<NB>(smem, a_dst, BM * 64, b_dst, s_in, av0, av1, breg);
+  const int KTS = BN * 32;
+  nt_gload<NB>(arow_ok, aptr, Bhi_g, b_src, KTS, 0, a0A, a1A, bA);
+  nt_swrite<NB>(smem, a_dst, BM * 64, b_dst, s_in, a0A, a1A, bA);
+  if (nk > 1) nt_gload<NB>(arow_ok, aptr, Bhi_g, b_src, KTS, 32, a0A, a1A, bA);      // stage 1 -> set A
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * STAGE;
-    const bool more = kt + 1 < nk;
-    if (more) nt_gload<NB>(arow_ok, aptr, Bhi_g, b_src, 32 * (kt + 1), av0, av1, breg);
-    compute_stage<1, NT_W>(cur, cur + BM * 64, cur + 2 * BM * 64, cur + 2 * BM * 64 + BN * 64, wm0, wn0, acc, lane,
-                           NT_W);
-    if (more) nt_swrite<NB>(smem + ((kt + 1) & 1) * STAGE, a_dst, BM * 64, b_dst, s_in, av0, av1, breg);
-    __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    {  // even stage kt: compute buf0; prefetch kt+2 into set B; then stage kt+1 (set A) -> buf1
+      if (kt + 2 < nk && !(dbg & 1)) nt_gload<NB>(arow_ok, aptr, Bhi_g, b_src, KTS, 32 * (kt + 2), a0B, a1B, bB);
+      if (!(dbg & 2))
+        compute_stage<1, NT_W>(smem, smem + BM * 64, smem + 2 * BM * 64, smem + 2 * BM * 64 + BN * 64, wm0, wn0, acc,
+                               lane, NT_W);
+      if (kt + 1 < nk) nt_swrite<NB>(smem + STAGE, a_dst, BM * 64, b_dst, s_in, a0A, a1A, bA);
+      __syncthreads();
+    }
+    if (kt + 1 < nk) {  // odd stage kt+1: compute buf1; prefetch kt+3 into set A; then stage kt+2 (set B) -> buf0
+      const char* cur = smem + STAGE;
+      if (kt + 3 < nk && !(dbg & 1)) nt_gload<NB>(arow_ok, aptr, Bhi_g, b_src, KTS, 32 * (kt + 3), a0A, a1A, bA);
+      if (!(dbg & 2))
+        compute_stage<1, NT_W>(cur, cur + BM * 64, cur + 2 * BM * 64, cur + 2 * BM * 64 + BN * 64, wm0, wn0, acc, lane,
+                               NT_W);
+      if (kt + 2 < nk) nt_swrite<NB>(smem, a_dst, BM * 64, b_dst, s_in, a0B, a1B, bB);
+      __syncthreads();
+    }
   }
 
   const int li = lane & 31, lh = lane >> 5;
+  if (dbg & 16) return;
 #pragma unroll
   for (int j = 0; j < NT_W; ++j) {
     const int col = wn0 + 32 * j + li;
@@ -292,12 +308,15 @@ __global__ void __launch_bounds__(XT) xgemm_tn_kernel(const float* __restrict__ 
     }
 }
 
-// O[Rp][Cp] planes from fp32 W[R][C]: O[r][c] = transpose ? W[c][r] : W[r][c], zero padded.
+// Planes of the logical matrix O[Rp][Cp] (O[r][c] = transpose ? W[c][r] : W[r][c], zero padded) from
+// fp32 W[R][C], stored STAGE-MAJOR: element (r, c) at [(c/32)][r][c%32], so that the [Rp][32] B tile
+// of one K stage is a single contiguous block (full-line, fully coalesced loads in the NT kernel).
 __global__ void split_weight_kernel(const float* __restrict__ W, int R, int C, int transpose, _Float16* hi,
                                     _Float16* lo, int Rp, int Cp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Rp * Cp) return;
-  const int r = i / Cp, c = i % Cp;
+  const int kt = i / (Rp * 32), rem = i % (Rp * 32);
+  const int r = rem / 32, c = 32 * kt + rem % 32;
   float v = 0.f;
   if (transpose) { if (c < R && r < C) v = W[(size_t)c * C + r]; }
   else { if (r < R && c < C) v = W[(size_t)r * C + c]; }
@@ -376,6 +395,7 @@ int launch_xgemm_nt(const float* A, int lda, int M, int Kp, const void* Bplanes,
   const dim3 grid(cdiv_i(M, 128));
   const double fl = 2.0 * M * (double)N * Kp, by = 4.0 * ((double)M * Kp + (double)M * N) + 4.0 * Np * Kp;
   if (Kp % 32 != 0 || lda % 4 != 0) return WGNN_ERR_SHAPE;
+  static const int dbg = getenv("WGNN_DBG_NT") ? atoi(getenv("WGNN_DBG_NT")) : 0;   // timing ablations only
 #define NT_CASE(NTW)                                                                                              \
   {                                                                                                               \
     const size_t smem = 2 * (size_t)(2 * 128 + 2 * 64 * NTW) * 64;                                                \
@@ -383,7 +403,7 @@ int launch_xgemm_nt(const float* A, int lda, int M, int Kp, const void* Bplanes,
     if (ensure_dyn_smem((const void*)xgemm_nt_kernel<NTW>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;           \
     PROF_LAUNCH("xgemm_nt_kernel<" #NTW ">", fl, by, st,                                                          \
                 hipLaunchKernelGGL(xgemm_nt_kernel<NTW>, grid, dim3(XT), smem, st, A, lda, M, Kp, bhi, blo, C, ldc, \
-                                   N, bias, s_in, s_out));                                                             \
+                                   N, bias, s_in, s_out, dbg));                                                             \
   }
   switch (Np) {
     case 64: NT_CASE(1) break;
