@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import torch
 
+from .distributed import allreduce_flat_
 from .functional import adam_step_, gcn_gru_backward_raw, gcn_gru_forward_raw, mse_loss_grad
 from .modules import GCN_GRU
 
@@ -48,7 +49,7 @@ class TrainStep:
     def step(self, A, X, L):
         loss, Y = self.forward_backward(A, X, L)
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat_g, group=self.group)     # RCCL sum over xGMI
+            allreduce_flat_(self.flat_g, self.group)                        # ONE RCCL sum over xGMI
         self.steps += 1
         adam_step_(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.steps, self.lr,
                    self.betas[0], self.betas[1], self.eps)                   # src/main.py:80
