@@ -76,12 +76,6 @@ def test_against_oracle_random(S, T, B, H, math):
     X = torch.rand(B, T, S, 13, generator=g)
     L = torch.rand(B, T, H, generator=g)
     p = orc.init_params(S, 13, H, seed=S + H)
-    if math == "f16x3" and S * 13 > 448:
-        from windgnn_amd import GCN_GRU
-        m = GCN_GRU(13, 13, 13, S * 13, H, math=math).to(dev)
-        with pytest.raises(RuntimeError, match="not supported"):     # loud, no silent fallback
-            m(A.to(dev), X.to(dev))
-        return
     Yo, loss_o, go = orc.train_step(A.double(), X.double(), L.double(), {k: v.double() for k, v in p.items()})
     model = _model_from(p, S, H, math)
     out, loss, grads = _run_step(model, A.to(dev), X.to(dev), L.to(dev))
@@ -152,6 +146,9 @@ def test_bitwise_run_to_run_determinism(math):
 def test_errors_are_loud():
     from windgnn_amd import GCN_GRU
     dev = _dev()
+    big = GCN_GRU(13, 13, 13, 65 * 13, 33, math="f16x3").to(dev)
+    with pytest.raises(RuntimeError, match="not supported"):     # > 64 stations: dense path not built, no fallback
+        big(torch.rand(65, 65, device=dev), torch.rand(1, 2, 65, 13, device=dev))
     m = GCN_GRU(13, 13, 13, 34 * 13, 102).to(dev)
     with pytest.raises(RuntimeError):                      # CPU tensors: no fallback
         m(torch.rand(34, 34), torch.rand(1, 4, 34, 13))

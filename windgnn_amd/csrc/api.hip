@@ -8,12 +8,12 @@ namespace {
 inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-  size_t BT, I, Ip, G3, Gp, H;
+  size_t BT, I, Ip, G3, Gp, H, Hp;
   int np_g3, np_i;                 // padded plane rows of the two split-weight images (f16x3)
   // forward workspace (float offsets)
   size_t ws_GI, ws_g, ws_planes_f, fwd_floats;
   // stash
-  size_t st_g, st_gates, stash_floats;
+  size_t st_g, st_gates, st_yp, stash_floats;
   // backward workspace
   size_t ws_dGI, ws_dGH, ws_dg, ws_part, ws_gcnpart, ws_planes_b, ws_scales, bwd_floats;
   int sk_ih, sk_hh;
@@ -23,6 +23,7 @@ int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
   int by_rows = (int)(BT / (size_t)min_rows);
   int by_grid = target_wgs / (tiles > 0 ? tiles : 1);
   int sk = by_rows < by_grid ? by_rows : by_grid;
+  if (sk >= 8) sk -= sk % 8;       // multiples of 8 keep the tiles of one K chunk on one XCD
   return sk < 1 ? 1 : sk;
 }
 
@@ -31,27 +32,29 @@ Layout make_layout(const wgnn_dims* d) {
   const bool x3 = d->math == WGNN_MATH_F16X3;
   L.BT = (size_t)d->B * d->T;
   L.I = (size_t)d->S * d->F;
-  L.Ip = rup(L.I, 32);
+  L.Ip = rup(L.I + (x3 ? 1 : 0), 32);       // f16x3: room for the ones column at index I
   L.H = d->H;
+  L.Hp = x3 ? (size_t)grux_hp(d->H) : 0;
   L.G3 = 3 * (size_t)d->H;
   L.Gp = rup(L.G3, 32);
-  L.np_g3 = xgemm_nt_np((int)L.G3);
-  L.np_i = xgemm_nt_np((int)L.I);
+  L.np_g3 = pgemm_nt_np((int)L.G3);
+  L.np_i = pgemm_nt_np((int)L.I);
   auto al = [](size_t x) { return align_up(x, 64); };
   const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : 0;   // 2 planes of halfs = that many floats
   const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : 0;
   size_t o = 0;
   L.ws_GI = o; o += al(L.BT * L.Gp);   // rows padded to 128-B multiples
-  L.ws_g = o; o += al(L.BT * L.Ip);
+  L.ws_g = o; o += al(L.BT * L.Ip);    // fp32 g (f32 mode) or its two fp16 planes (f16x3): same bytes
   L.ws_planes_f = o; o += al(planes_f);
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
   L.st_gates = o; o += al(L.BT * 4 * L.H);
+  L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
   L.stash_floats = o;
   if (x3) {
-    L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.I + 1, 128), 256, 64);
-    L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.H + 1, 128), 256, 64);
+    L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 160) * cdiv_i((int)L.I + 1, 128), 512, 64);
+    L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 160) * cdiv_i((int)L.H + 1, 128), 512, 64);
   } else {
     L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128), 1024, 256);
     L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128), 1024, 256);
@@ -59,7 +62,7 @@ Layout make_layout(const wgnn_dims* d) {
   size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
   size_t part_hh = (size_t)L.sk_hh * L.G3 * (L.H + 1);
   o = 0;
-  L.ws_dGI = o; o += al(L.BT * L.Gp);
+  L.ws_dGI = o; o += al(L.BT * L.Gp);   // fp32, or hi+lo fp16 planes (same bytes)
   L.ws_dGH = o; o += al(L.BT * L.Gp);
   L.ws_dg = o; o += al(L.BT * L.I);
   L.ws_part = o; o += al(part_ih > part_hh ? part_ih : part_hh);
@@ -82,10 +85,7 @@ int check_dims(const wgnn_dims* d) {
   if (d->S > 64) return WGNN_ERR_UNSUPPORTED;       // dense LDS-resident adjacency path
   if (d->math == WGNN_MATH_F32 && !gru_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
   if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3) return WGNN_ERR_DTYPE;
-  if (d->math == WGNN_MATH_F16X3) {
-    // split-fp16 GEMM tiles cover all of N in one workgroup: 3H <= 320 (TN) and S*13 <= 448
-    if (3 * d->H > 320 || d->S * d->F > 448 || !grux_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
-  }
+  if (d->math == WGNN_MATH_F16X3 && !grux_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
   return WGNN_OK;
 }
 
@@ -103,7 +103,7 @@ const char* wgnn_strerror(int status) {
     case WGNN_ERR_DTYPE: return "unsupported dtype / math mode";
     case WGNN_ERR_WORKSPACE: return "workspace or stash too small";
     case WGNN_ERR_UNSUPPORTED:
-      return "configuration not supported by this build (dense S <= 64, H <= 110; f16x3: S <= 34, H <= 106)";
+      return "configuration not supported by this build (dense S <= 64; H <= 110 in f32 mode, <= 127 in f16x3)";
     case WGNN_ERR_HIP: return "HIP runtime error (kernel launch failed)";
     default: return "unknown status";
   }
@@ -138,30 +138,31 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   float* gates = sf ? sf + L.st_gates : nullptr;
   const bool x3 = d->math == WGNN_MATH_F16X3;
 
-  if (x3) {   // split W_ih once per call: 2 fp16 planes [np_g3][Ip]
-    rc = launch_split_weight(p->w_ih, (int)L.G3, (int)L.I, 0, ws + L.ws_planes_f, L.np_g3, (int)L.Ip, st);
+  if (x3) {
+    // W_ih as stage-major fp16 planes [np_g3][Ip] with b_ih folded into column I (g's ones column)
+    rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, (int)L.I, ws + L.ws_planes_f, L.np_g3,
+                              (int)L.Ip, st);
     if (rc != WGNN_OK) return rc;
-  }
-  if (x3)
     rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
                           (int)L.Ip, st);
-  else
-    rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                         (int)L.Ip, st);
-  if (rc != WGNN_OK) return rc;
-  if (x3) {
-    rc = launch_xgemm_nt(g, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI, (int)L.Gp, (int)L.G3,
-                         p->b_ih, nullptr, nullptr, st);
-  } else {
-    GemmArgs ga = {};
-    ga.A = g; ga.lda = (int)L.Ip; ga.a_kcontig = 1;
-    ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
-    ga.C = GI; ga.ldc = (int)L.Gp; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
-    ga.bias = p->b_ih; ga.splitk = 1;
-    rc = launch_gemm_f32(ga, st);
+    if (rc != WGNN_OK) return rc;
+    const _Float16* ghi = (const _Float16*)g;
+    rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
+                         (int)L.Gp, (int)L.G3, nullptr, st);
+    if (rc != WGNN_OK) return rc;
+    return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
+                           st);
   }
+  rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
+                       (int)L.Ip, st);
   if (rc != WGNN_OK) return rc;
-  if (x3) return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, st);
+  GemmArgs ga = {};
+  ga.A = g; ga.lda = (int)L.Ip; ga.a_kcontig = 1;
+  ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
+  ga.C = GI; ga.ldc = (int)L.Gp; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
+  ga.bias = p->b_ih; ga.splitk = 1;
+  rc = launch_gemm_f32(ga, st);
+  if (rc != WGNN_OK) return rc;
   return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, st);
 }
 
@@ -189,35 +190,45 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   const bool x3 = d->math == WGNN_MATH_F16X3;
 
   if (x3) {
+    // Everything downstream of dY is linear in it: run it in units scaled by scales[0] = 2^k (so that
+    // fp16 never sees ~1e-9 values) and multiply only the final gradients by scales[1] = 2^-k.
     rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
     if (rc != WGNN_OK) return rc;
-  }
-  // f16x3: dGI/dGH (and everything derived from them, dg included) stay in units scaled by scales[0];
-  // only the final gradients are multiplied by scales[1].
-  if (x3) rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGI, dGH, (int)L.Gp, st);
-  else rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
-  if (rc != WGNN_OK) return rc;
-
-  if (x3) {
-    // dW_hh = dGH^T [Hprev | 1]
-    rc = launch_xgemm_tn(dGH, (int)L.Gp, (int)L.G3, Y, (int)L.H, (int)L.H, (int)L.H, d->T, (int)L.BT, L.sk_hh, part,
-                         (int)L.G3, (int)L.H + 1, nullptr, st);
+    _Float16* dGIh = (_Float16*)dGI;
+    _Float16* dGHh = (_Float16*)dGH;
+    const _Float16* gh = (const _Float16*)gact;
+    const _Float16* yph = (const _Float16*)(sf + L.st_yp);
+    const size_t PG = L.BT * L.Gp;
+    rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, st);
+    if (rc != WGNN_OK) return rc;
+    // dW_hh | db_hh = dGH^T [Hprev | 1]   (Hprev row (b,t) = Y-plane row (b,t-1), zero at t = 0)
+    rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT, L.sk_hh, part,
+                         (int)L.G3, (int)L.H + 1, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales, st);
     if (rc != WGNN_OK) return rc;
-    // dW_ih = dGI^T [g | 1]
-    rc = launch_xgemm_tn(dGI, (int)L.Gp, (int)L.G3, gact, (int)L.Ip, (int)L.I, (int)L.I, 0, (int)L.BT, L.sk_ih, part,
-                         (int)L.G3, (int)L.I + 1, nullptr, st);
+    // dW_ih | db_ih = dGI^T [g | 1]
+    rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part,
+                         (int)L.G3, (int)L.I + 1, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales, st);
     if (rc != WGNN_OK) return rc;
-    // dg = dGI W_ih  (B operand = split(W_ih^T) [np_i][Gp])
-    rc = launch_split_weight(p->w_ih, (int)L.G3, (int)L.I, 1, ws + L.ws_planes_b, L.np_i, (int)L.Gp, st);
+    // dg = dGI W_ih   (B operand = split(W_ih^T) [np_i][Gp]); dg stays in scaled units
+    rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, ws + L.ws_planes_b, L.np_i, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;
-    rc = launch_xgemm_nt(dGI, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I, (int)L.I,
-                         nullptr, nullptr, nullptr, st);
+    rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I,
+                         (int)L.I, nullptr, st);
     if (rc != WGNN_OK) return rc;
-  } else {
+    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
+                          scales, /*scale_in=*/0, ws + L.ws_gcnpart, st);
+    if (rc != WGNN_OK) return rc;
+    return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT), g->conv1_weight, g->conv1_bias,
+                                     g->conv2_weight, g->conv2_bias, st);
+  }
+
+  rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
+  if (rc != WGNN_OK) return rc;
+  {
     // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
     GemmArgs a = {};
     a.A = dGH; a.lda = (int)L.Gp; a.a_kcontig = 0;
@@ -245,14 +256,6 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     c.C = dg; c.ldc = (int)L.I; c.M = (int)L.BT; c.N = (int)L.I; c.K = (int)L.G3; c.splitk = 1;
     rc = launch_gemm_f32(c, st);
     if (rc != WGNN_OK) return rc;
-  }
-
-  if (x3) {
-    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
-                          scales, /*scale_in=*/0, ws + L.ws_gcnpart, st);
-    if (rc != WGNN_OK) return rc;
-    return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT), g->conv1_weight, g->conv1_bias,
-                                     g->conv2_weight, g->conv2_bias, st);
   }
   return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                          g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);

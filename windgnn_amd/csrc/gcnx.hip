@@ -101,12 +101,12 @@ struct LinMap {            // element i = lane + 64k of a linear [S*13] tile <->
   }
 };
 
-template <int NE>
-__device__ __forceinline__ void gload_lin(float (&r)[NE], const float* __restrict__ src, int lane, int I) {
+template <int NE, class TSRC>
+__device__ __forceinline__ void gload_lin(float (&r)[NE], const TSRC* __restrict__ src, int lane, int I) {
 #pragma unroll
   for (int k = 0; k < NE; ++k) {
     const int i = lane + 64 * k;
-    r[k] = src[i < I ? i : I - 1];            // clamped, unconditional: no exec-mask branches
+    r[k] = (float)src[i < I ? i : I - 1];     // clamped, unconditional: no exec-mask branches
   }
 }
 
@@ -124,17 +124,23 @@ template <int NT>
 __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
-                                                       const float* __restrict__ b2, float* __restrict__ out,
-                                                       int ld_out) {
+                                                       const float* __restrict__ b2, _Float16* __restrict__ ghi,
+                                                       _Float16* __restrict__ glo, int ldp) {
   constexpr int KS = (NT + 1) / 2;
   constexpr int SP = 16 * NT;
   constexpr int NE = (SP * F13 + 63) / 64;
+  static_assert(SP * XS * 4 >= 2 * (SP * F13 + 64) * 2, "output staging must fit the second buffer");
   __shared__ __attribute__((aligned(16))) float sbuf[4 * 2 * SP * XS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int I = S * F13;
   float* xb = sbuf + wave * 2 * SP * XS;
-  float* ob = xb + SP * XS;
+  // output staging: the tile's g row as it lies in HBM, [ldp] halfs per plane (hi then lo)
+  _Float16* obh = (_Float16*)(xb + SP * XS);
+  _Float16* obl = obh + ldp;
   for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;   // pads (f >= 13, s >= S) stay zero forever
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0 && I < ldp) obh[I] = (_Float16)1.f;           // ones column: yields b_ih / db_ih in the GEMMs
 
   Frag CA[NT][KS];
   build_A_frags<NT, KS, false>(CA, A, S, c, g);
@@ -166,7 +172,7 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
 
   float xr[NE];
   if (wave_id < ntiles) {
-    gload_lin<NE>(xr, X + (size_t)wave_id * I, lane, I);
+    gload_lin<NE, float>(xr, X + (size_t)wave_id * I, lane, I);
 #pragma unroll
     for (int k = 0; k < NE; ++k)
       if (lane + 64 * k < I) xb[map.off[k]] = xr[k];
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     wave_lds_fence();                                 // this tile's X is staged
     const bool more = tile + nwaves < ntiles;
-    if (more) gload_lin<NE>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch the next tile
+    if (more) gload_lin<NE, float>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch the next tile
 
     f32x4 U[NT];
 #pragma unroll
@@ -200,10 +206,19 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
       f32x4 acc = zero4;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = mfma3(UF[ks], CA[n][ks], acc);
-      f32x4 v;
+      const int s_ = 16 * n + c;
+      if (s_ < S) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bb2[r], 0.f);
-      *(f32x4*)(ob + (16 * n + c) * XS + 4 * g) = v;           // g^T[f' = 4g..4g+3][s] -> staged [s][f']
+        for (int r = 0; r < 4; ++r) {
+          const int f = 4 * g + r;
+          if (f < F13) {
+            const float v = fmaxf(acc[r] + bb2[r], 0.f);
+            const _Float16 h = (_Float16)v;
+            obh[s_ * F13 + f] = h;
+            obl[s_ * F13 + f] = (_Float16)(v - (float)h);
+          }
+        }
+      }
     }
     wave_lds_fence();
     // Stage the NEXT tile's X now (xb was last read by the U1 products above), i.e. wait for the
@@ -213,13 +228,16 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
       for (int k = 0; k < NE; ++k)
         if (lane + 64 * k < I) xb[map.off[k]] = xr[k];
     }
-    float* dst = out + (size_t)tile * ld_out;
-#pragma unroll
-    for (int k = 0; k < NE; ++k) {
-      const int i = lane + 64 * k;
-      if (i < I) dst[i] = ob[map.off[k]];
+    {  // coalesced dword copy-out of both planes (row pitch ldp halfs; pads: col I = 1, rest 0)
+      unsigned* dh = (unsigned*)(ghi + (size_t)tile * ldp);
+      unsigned* dl = (unsigned*)(glo + (size_t)tile * ldp);
+      const unsigned* sh = (const unsigned*)obh;
+      const unsigned* sl = (const unsigned*)obl;
+      for (int d = lane; d < ldp / 2; d += 64) {
+        dh[d] = sh[d];
+        dl[d] = sl[d];
+      }
     }
-    for (int i = I + lane; i < ld_out; i += 64) dst[i] = 0.f;   // K padding of the projection GEMM
   }
 }
 
@@ -237,7 +255,7 @@ template <int NT>
 __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
-                                                       const float* __restrict__ gact, int ld_g,
+                                                       const _Float16* __restrict__ gact, int ld_g,
                                                        const float* __restrict__ dg, const float* __restrict__ scales,
                                                        int scale_in, float* __restrict__ partial) {
   constexpr int KS = (NT + 1) / 2;
@@ -314,9 +332,9 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
 
   float xr[NE], gr[NE], dr[NE];
   if (wave_id < ntiles) {
-    gload_lin<NE>(xr, X + (size_t)wave_id * I, lane, I);
-    gload_lin<NE>(gr, gact + (size_t)wave_id * ld_g, lane, I);
-    gload_lin<NE>(dr, dg + (size_t)wave_id * I, lane, I);
+    gload_lin<NE, float>(xr, X + (size_t)wave_id * I, lane, I);
+    gload_lin<NE, _Float16>(gr, gact + (size_t)wave_id * ld_g, lane, I);
+    gload_lin<NE, float>(dr, dg + (size_t)wave_id * I, lane, I);
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     asm volatile("" ::: "memory");   // keep the A / A^T fragment reads in LDS (no hoisting into 96 VGPRs)
@@ -330,9 +348,9 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
     wave_lds_fence();
     if (tile + nwaves < ntiles) {                               // prefetch the next tile under this one's math
       const size_t nt = (size_t)(tile + nwaves);
-      gload_lin<NE>(xr, X + nt * I, lane, I);
-      gload_lin<NE>(gr, gact + nt * ld_g, lane, I);
-      gload_lin<NE>(dr, dg + nt * I, lane, I);
+      gload_lin<NE, float>(xr, X + nt * I, lane, I);
+      gload_lin<NE, _Float16>(gr, gact + nt * ld_g, lane, I);
+      gload_lin<NE, float>(dr, dg + nt * I, lane, I);
     }
     // ---- recompute U1, H1 [s][f]
     f32x4 U[NT];
@@ -452,13 +470,15 @@ size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)grid_x(ntiles) * PA
 int gcnx_bwd_grid(int ntiles) { return grid_x(ntiles); }
 
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, float* g, int ldg, hipStream_t st) {
+                     const float* W2, const float* b2, void* g_planes, int ldg, hipStream_t st) {
+  _Float16* ghi = (_Float16*)g_planes;
+  _Float16* glo = ghi + (size_t)ntiles * ldg;
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
   const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
   const dim3 grid(grid_x(ntiles));
 #define FWD_CASE(NT)                                                                                              \
   PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                             \
-              hipLaunchKernelGGL(gcnx_fwd_kernel<NT>, grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, b2, g, ldg))
+              hipLaunchKernelGGL(gcnx_fwd_kernel<NT>, grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, b2, ghi, glo, ldg))
   switch ((S + 15) / 16) {
     case 1: FWD_CASE(1); break;
     case 2: FWD_CASE(2); break;
@@ -472,8 +492,9 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const fl
 }
 
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* g, int ldg, const float* dg, const float* scales, int scale_in,
-                     float* partial, hipStream_t st) {
+                     const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
+                     int scale_in, float* partial, hipStream_t st) {
+  const _Float16* g = (const _Float16*)g_planes;   // hi plane carries the sign: g > 0 <=> hi > 0
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
   const dim3 grid(grid_x(ntiles));

@@ -48,17 +48,25 @@ __device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, f
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int KS>   // K steps of 32 over the hidden index: KS = ceil(H/32)
+template <int KS>   // K steps of 32 over the hidden index (+ the ones column): KS = ceil((H+1)/32)
 __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const float* __restrict__ GI, int ldgi,
                                                             const float* __restrict__ Whh,
                                                             const float* __restrict__ bhh, float* __restrict__ Y,
-                                                            float* __restrict__ gates) {
+                                                            float* __restrict__ gates, _Float16* __restrict__ yp_hi,
+                                                            _Float16* __restrict__ yp_lo) {
+  constexpr int HP = 32 * KS;                      // plane row width (halfs): h, then 1.0 at column H, then 0
   constexpr int HS = 32 * KS + 8;                  // row stride in halfs: 16-B aligned, conflict-free reads
   __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * MB * HS];
   _Float16* hhi = hbuf;
   _Float16* hlo = hbuf + MB * HS;
   for (int i = threadIdx.x; i < 2 * MB * HS; i += NTHREADS) hbuf[i] = (_Float16)0.f;
+  __syncthreads();
+  if (threadIdx.x < MB) hhi[threadIdx.x * HS + H] = (_Float16)1.f;   // ones column (W_hh fragments are 0 there)
 
+  if (yp_hi && blockIdx.x == 0 && threadIdx.x < HP) {   // row B*T: what [Hprev | 1] looks like at t = 0
+    yp_hi[(size_t)B * T * HP + threadIdx.x] = (_Float16)(threadIdx.x == H ? 1.f : 0.f);
+    yp_lo[(size_t)B * T * HP + threadIdx.x] = (_Float16)0.f;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int j = 16 * wave + c;
   const bool active = 16 * wave < H;               // wave-uniform
@@ -151,6 +159,17 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       for (int r = 0; r < 4; ++r) put_split(hhi, hlo, (4 * g + r) * HS + j, hnew[r]);
     }
     __syncthreads();
+    if (yp_hi) {   // h_t as fp16 planes (the B operand of the dW_hh GEMM): 16-byte chunks straight from LDS
+      for (int q = threadIdx.x; q < 2 * MB * (HP / 8); q += NTHREADS) {
+        const int plane = q / (MB * (HP / 8)), rem = q % (MB * (HP / 8));
+        const int m = rem / (HP / 8), ch = rem % (HP / 8);
+        const int b = b0 + m;
+        if (b < B) {
+          const h8 v = *(const h8*)((plane ? hlo : hhi) + m * HS + 8 * ch);
+          *(h8*)((plane ? yp_lo : yp_hi) + ((size_t)b * T + t) * HP + 8 * ch) = v;
+        }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -167,13 +186,19 @@ template <int KS3>   // K steps of 32 over the 3H gate rows
 __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
                                                             const float* __restrict__ Y, const float* __restrict__ dY,
                                                             const float* __restrict__ gates,
-                                                            const float* __restrict__ scales, float* __restrict__ dGI,
-                                                            float* __restrict__ dGH, int ldd) {
+                                                            const float* __restrict__ scales,
+                                                            _Float16* __restrict__ dGI_hi, _Float16* __restrict__ dGI_lo,
+                                                            _Float16* __restrict__ dGH_hi, _Float16* __restrict__ dGH_lo,
+                                                            int ldd) {
   constexpr int DS = 32 * KS3 + 8;
-  __shared__ __attribute__((aligned(16))) _Float16 dbuf[2 * MB * DS];
+  // two [16][DS] fp16 hi/lo tiles: dgh = [dar|daz|dnt*r] (also the MFMA A operand) and dgi = [dar|daz|dnt];
+  // both are copied out as 16-byte chunks into the dGH / dGI planes (K padding columns stay zero).
+  __shared__ __attribute__((aligned(16))) _Float16 dbuf[4 * MB * DS];
   _Float16* dhi = dbuf;
   _Float16* dlo = dbuf + MB * DS;
-  for (int i = threadIdx.x; i < 2 * MB * DS; i += NTHREADS) dbuf[i] = (_Float16)0.f;
+  _Float16* ihi = dbuf + 2 * MB * DS;
+  _Float16* ilo = dbuf + 3 * MB * DS;
+  for (int i = threadIdx.x; i < 4 * MB * DS; i += NTHREADS) dbuf[i] = (_Float16)0.f;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int j = 16 * wave + c;
@@ -194,15 +219,6 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
       x[jj] = (jv && k < G3) ? Whh[(size_t)k * H + j] : 0.f;
     }
     WT[ks] = split_vals(x);
-  }
-  {  // zero the K-padding columns [3H, ldd) of this workgroup's dGI/dGH rows
-    const int npad = ldd - G3;
-    const int nrows = min(MB, B - b0) * T;
-    for (int i = threadIdx.x; i < nrows * npad; i += NTHREADS) {
-      const size_t o = ((size_t)b0 * T + i / npad) * ldd + G3 + i % npad;
-      dGI[o] = 0.f;
-      dGH[o] = 0.f;
-    }
   }
   size_t rowoff[4];
   bool rowok[4];
@@ -254,17 +270,28 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
           put_split(dhi, dlo, m * DS + j, dar);
           put_split(dhi, dlo, m * DS + H + j, daz);
           put_split(dhi, dlo, m * DS + 2 * H + j, dnr);
-        }
-        if (rowok[r]) {
-          const size_t bt = rowoff[r] + t;
-          float* gi = dGI + bt * ldd + j;
-          float* gh = dGH + bt * ldd + j;
-          gi[0] = dar; gi[H] = daz; gi[2 * H] = dnt;
-          gh[0] = dar; gh[H] = daz; gh[2 * H] = dnr;
+          ihi[m * DS + j] = dhi[m * DS + j];
+          ilo[m * DS + j] = dlo[m * DS + j];
+          ihi[m * DS + H + j] = dhi[m * DS + H + j];
+          ilo[m * DS + H + j] = dlo[m * DS + H + j];
+          put_split(ihi, ilo, m * DS + 2 * H + j, dnt);
         }
       }
     }
     __syncthreads();
+    {  // planes out: rows (b, t) of dGH and dGI, ldd/8 chunks of 16 B per row and plane
+      const int cpr = ldd / 8;
+      for (int q = threadIdx.x; q < 4 * MB * cpr; q += NTHREADS) {
+        const int buf = q / (MB * cpr), rem = q % (MB * cpr);
+        const int m = rem / cpr, ch = rem % cpr;
+        const int b = b0 + m;
+        if (b < B) {
+          const h8 v = *(const h8*)(dbuf + (size_t)buf * MB * DS + m * DS + 8 * ch);
+          _Float16* dst = buf == 0 ? dGH_hi : (buf == 1 ? dGH_lo : (buf == 2 ? dGI_hi : dGI_lo));
+          *(h8*)(dst + ((size_t)b * T + t) * ldd + 8 * ch) = v;
+        }
+      }
+    }
     if (active && t > 0) {
 #pragma unroll
       for (int ks = 0; ks < KS3; ++ks) {
@@ -282,17 +309,21 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 
 }  // namespace
 
-bool grux_shape_supported(int H) { return H >= 1 && H <= 128; }
+bool grux_shape_supported(int H) { return H >= 1 && H <= 127; }
+
+int grux_hp(int H) { return 32 * cdiv_i(H + 1, 32); }
 
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                    float* gates, hipStream_t st) {
+                    float* gates, void* y_planes /*nullable: 2 x [B*T][grux_hp(H)] halfs*/, hipStream_t st) {
+  _Float16* yh = (_Float16*)y_planes;
+  _Float16* yl = yh ? yh + ((size_t)B * T + 1) * grux_hp(H) : nullptr;   // each plane has B*T + 1 rows
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0));
   const dim3 grid(cdiv_i(B, MB));
 #define FCASE(K)                                                                                                   \
   PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                               \
-              hipLaunchKernelGGL(grux_fwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, Y, gates))
-  switch (cdiv_i(H, 32)) {
+              hipLaunchKernelGGL(grux_fwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, Y, gates, yh, yl))
+  switch (cdiv_i(H + 1, 32)) {
     case 1: FCASE(1); break;
     case 2: FCASE(2); break;
     case 3: FCASE(3); break;
@@ -305,14 +336,19 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
 }
 
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
-                    const float* scales, float* dGI, float* dGH, int ldd, hipStream_t st) {
+                    const float* scales, void* dGI_planes, void* dGH_planes, int ldd, hipStream_t st) {
+  _Float16* ih = (_Float16*)dGI_planes;
+  _Float16* il = ih + (size_t)B * T * ldd;
+  _Float16* hh = (_Float16*)dGH_planes;
+  _Float16* hl = hh + (size_t)B * T * ldd;
+  if (ldd % 8 != 0 || ldd > 32 * cdiv_i(3 * H, 32)) return WGNN_ERR_SHAPE;
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (4 * H + 2 * H + 6 * H);
   const dim3 grid(cdiv_i(B, MB));
 #define BCASE(K)                                                                                                   \
   PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                               \
               hipLaunchKernelGGL(grux_bwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, gates, scales, \
-                                 dGI, dGH, ldd))
+                                 ih, il, hh, hl, ldd))
   switch (cdiv_i(3 * H, 32)) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;
