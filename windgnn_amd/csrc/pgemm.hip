@@ -15,6 +15,8 @@
 // TN operands are K-strided in memory, so tiles are staged row-major [k][cols] exactly as they lie
 // in HBM and the MFMA fragments are formed by ds_read_b64_tr_b16 (hardware transpose read); the row
 // stride of 320 B (== 64 mod 256) makes the 4 rows x 64 B touched by a half-wave conflict-free.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -39,11 +41,13 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
                                                          const _Float16* __restrict__ Alo, int lda, int M, int Kp,
                                                          const _Float16* __restrict__ Bpl, int Np,
                                                          float* __restrict__ C, int ldc, int N,
-                                                         const float* __restrict__ s_out_p, int nm, int nslices) {
+                                                         const float* __restrict__ s_out_p, int nm, int nslices,
+                                                         int dbg) {
   constexpr int BM = 128, BN = 32 * NT_W, STAGE = (2 * BM + 2 * BN) * 64;
-  constexpr int NA = (2 * BM * 4) / PT, NB = (2 * BN * 4 + PT - 1) / PT;
+  constexpr int RING = 2;   // 2 x 36 KB stages => two workgroups per CU (measured: beats a 4-deep ring at 1 WG/CU, 111 vs 174 us)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases go to M0
   // blocks {b, b+8, ...} (same XCD, dispatched together) are the N slices of one M tile: the A tile is
   // fetched from HBM once and re-read from that XCD's L2 by the sibling slices.
   const int grp = blockIdx.x / (8 * nslices), within = blockIdx.x % (8 * nslices);
@@ -58,53 +62,52 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const _Float16* a_src[NA];
-  int a_dst[NA];
+  // ---- LDS-DMA staging (global_load_lds_dwordx4): no VGPRs, no ds_write, and no compiler-inserted
+  // vmcnt waits in the way (with register staging hipcc waited for the NEW loads before every
+  // ds_write of the OLD ones, so loads never overlapped the MFMAs).  One wave-instruction moves a
+  // 1 KB "piece" = 16 tile rows x 64 B; the LDS image is lane-linear, so the XOR swizzle the fragment
+  // reads expect is applied to the SOURCE chunk index: LDS (row, pos) <- global chunk pos ^ ((row>>2)&3).
+  constexpr int APIECES = 2 * BM / 16, BPIECES = 2 * BN / 16;          // per stage
+  constexpr int NPA = APIECES / 4, NPB = (BPIECES + 3) / 4;            // per wave
+  const int prow = lane >> 2, ppos = lane & 3;
+  const _Float16* a_src[NPA];
+  int a_dst[NPA];
 #pragma unroll
-  for (int it = 0; it < NA; ++it) {
-    const int q = tid + PT * it;
-    const int plane = q / (BM * 4), rem = q % (BM * 4);
-    const int row = rem >> 2, c = rem & 3;
+  for (int it = 0; it < NPA; ++it) {
+    const int p = wave + 4 * it;
+    const int plane = p / (BM / 16), row = 16 * (p % (BM / 16)) + prow;
     const int gr = min(m0 + row, M - 1);                 // rows past M are computed but never stored
-    a_src[it] = (plane ? Alo : Ahi) + (size_t)gr * lda + 8 * c;
-    a_dst[it] = plane * BM * 64 + sw_off(row, c);
+    a_src[it] = (plane ? Alo : Ahi) + (size_t)gr * lda + 8 * (ppos ^ ((row >> 2) & 3));
+    a_dst[it] = plane * BM * 64 + 16 * (p % (BM / 16)) * 64;            // wave-uniform piece base
   }
-  const _Float16* b_src[NB];
-  int b_dst[NB];
-  bool b_on[NB];
+  const _Float16* b_src[NPB];
+  int b_dst[NPB];
+  bool b_on[NPB];
 #pragma unroll
-  for (int it = 0; it < NB; ++it) {
-    const int q = tid + PT * it;
-    b_on[it] = q < 2 * BN * 4;
-    const int qq = b_on[it] ? q : 0;
-    const int plane = qq / (BN * 4), rem = qq % (BN * 4);
-    const int row = rem >> 2, c = rem & 3;
-    b_src[it] = Bpl + (size_t)plane * Np * Kp + (size_t)(n0 + row) * 32 + 8 * c;   // + kt * Np * 32
-    b_dst[it] = 2 * BM * 64 + plane * BN * 64 + sw_off(row, c);
+  for (int it = 0; it < NPB; ++it) {
+    const int p = wave + 4 * it;
+    b_on[it] = p < BPIECES;                              // wave-uniform
+    const int pp = b_on[it] ? p : 0;
+    const int plane = pp / (BN / 16), row = 16 * (pp % (BN / 16)) + prow;
+    b_src[it] = Bpl + (size_t)plane * Np * Kp + (size_t)(n0 + row) * 32 + 8 * (ppos ^ ((row >> 2) & 3));
+    b_dst[it] = 2 * BM * 64 + plane * BN * 64 + 16 * (pp % (BN / 16)) * 64;
   }
-  u32x4 ra[NA], rb[NB];
   const int nk = Kp / 32;
   const size_t bkt = (size_t)Np * 32;
-
-#define NT_LOAD(kt)                                                                      \
-  do {                                                                                   \
-    _Pragma("unroll") for (int it = 0; it < NA; ++it) ra[it] = *(const u32x4*)(a_src[it] + 32 * (kt)); \
-    _Pragma("unroll") for (int it = 0; it < NB; ++it) rb[it] = *(const u32x4*)(b_src[it] + bkt * (kt)); \
-  } while (0)
-#define NT_STORE(st)                                                                     \
-  do {                                                                                   \
-    _Pragma("unroll") for (int it = 0; it < NA; ++it) *(u32x4*)((st) + a_dst[it]) = ra[it]; \
-    _Pragma("unroll") for (int it = 0; it < NB; ++it) if (b_on[it]) *(u32x4*)((st) + b_dst[it]) = rb[it]; \
-  } while (0)
-
-  NT_LOAD(0);
-  NT_STORE(smem);
-  __syncthreads();
   const int li = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * STAGE;
-    const bool more = kt + 1 < nk;
-    if (more) NT_LOAD(kt + 1);
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+
+  auto dma_stage = [&](char* st, int kt) {
+#pragma unroll
+    for (int it = 0; it < NPA; ++it)
+      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[it] + 32 * kt), (lds_void*)(st + a_dst[it]), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < NPB; ++it)
+      if (b_on[it])
+        __builtin_amdgcn_global_load_lds((glb_void*)(b_src[it] + bkt * kt), (lds_void*)(st + b_dst[it]), 16, 0, 0);
+  };
+  auto compute = [&](const char* cur) {
     const char* Ah = cur;
     const char* Al = cur + BM * 64;
     const char* Bh = cur + 2 * BM * 64;
@@ -125,11 +128,27 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
         acc[j] = mfma_h(ah, bh, acc[j]);
       }
     }
-    if (more) NT_STORE(smem + ((kt + 1) & 1) * STAGE);
-    __syncthreads();
+  };
+
+  // RING-deep LDS ring: stage kt+RING-1 is issued while stage kt is multiplied, so RING-1 stages of
+  // DMA are in flight per workgroup (the kernel is bound by memory latency x bytes in flight, not by
+  // issue).  vmcnt is counted: (RING-2) stages * (NPA+NPB) DMA instructions may stay outstanding.
+  constexpr int PER = NPA + NPB;
+  static_assert(BPIECES % 4 == 0, "every wave must issue the same number of DMA instructions per stage");
+#pragma unroll
+  for (int s0 = 0; s0 < RING - 1; ++s0)
+    if (s0 < nk) dma_stage(smem + s0 * STAGE, s0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed once at most the DMA of the (up to RING-2) younger stages is outstanding
+    const int younger = min(RING - 2, nk - 1 - kt);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // all waves: stage kt visible, stage kt-1 no longer being read
+    if (kt + RING - 1 < nk && !(dbg & 1)) dma_stage(smem + ((kt + RING - 1) % RING) * STAGE, kt + RING - 1);
+    if (!(dbg & 2)) compute(smem + (kt % RING) * STAGE);
   }
-#undef NT_LOAD
-#undef NT_STORE
+  if (dbg & 16) return;
 
 #pragma unroll
   for (int j = 0; j < NT_W; ++j) {
@@ -327,6 +346,7 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
                     int ldc, int N, const float* s_out, hipStream_t st) {
   if (Kp % 32 != 0 || lda % 8 != 0 || Np % 160 != 0) return WGNN_ERR_SHAPE;
   constexpr int NTW = 5;
+  static const int dbg = getenv("WGNN_DBG_NT") ? atoi(getenv("WGNN_DBG_NT")) : 0;   // timing ablations only
   const int nm = cdiv_i(M, 128), nslices = Np / 160;
   const int grid = cdiv_i(nm, 8) * 8 * nslices;
   const size_t smem = 2 * (size_t)(2 * 128 + 2 * 32 * NTW) * 64;
@@ -336,7 +356,7 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
   PROF_LAUNCH("pgemm_nt_kernel<5>", fl, by, st,
               hipLaunchKernelGGL(pgemm_nt_kernel<NTW>, dim3(grid), dim3(PT), smem, st, (const _Float16*)Ahi,
                                  (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, C, ldc, N, s_out, nm,
-                                 nslices));
+                                 nslices, dbg));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
