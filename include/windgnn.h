@@ -130,6 +130,22 @@ int wgnn_mse_loss_grad(const float* Y, const float* L, int64_t n, float grad_sca
 int wgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    int32_t step, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* N2 (src/step4_sequence_preparer.py:7-21): gather B windows of seq_len steps out of a device-resident
+ * feature array feat[Ttot][S][F] (the 13 feature columns, i.e. the reference's columns 2:15):
+ *   X[b][t][s][f]   = feat[t0_b + t][s][f]
+ *   L[b][t][k*S+s]  = feat[t0_b + t + k + 1][s][label_feat],  k = 0,1,2   (+1/+2/+3 h labels; the
+ *                     reference's label column 13 is feature index 11)
+ * t0_b = starts[b] (device int32 array; the same values on the host in starts_host for validation), or
+ * b*seq_len when both are NULL (the reference's non-overlapping windows, :10-13).  Every window needs
+ * t0 + seq_len + 3 <= Ttot, else WGNN_ERR_SHAPE (the reference would build a ragged array there). */
+int wgnn_make_windows(const float* feat, int64_t Ttot, int32_t S, int32_t F, int32_t seq_len,
+                      int32_t label_feat, const int32_t* starts_host, const int32_t* starts_dev,
+                      int32_t B, float* X, float* L, void* stream);
+
+/* N4 (src/main.py:103,116,131,146): out[b][j] = Y[b][T-1][j] * (wind_max - wind_min) + wind_min. */
+int wgnn_predict_last(const float* Y, int32_t B, int32_t T, int32_t H, float wind_min, float wind_max,
+                      float* out, void* stream);
+
 /* Measurement aid for bench.py (no reference counterpart): while enabled, every kernel launch made
  * by this library is bracketed by hipEvents on its stream and tallied per kernel symbol together
  * with its algorithmic flops/bytes.  wgnn_profile_read(idx, ...) synchronises the device and

@@ -68,3 +68,17 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_build_graph_matches_reference_output():
+    """N1: windgnn_amd.graph against the adjacency the reference's build_graph produced (golden)."""
+    import numpy as np
+    import pandas as pd
+    from conftest import GOLDEN
+    from windgnn_amd.graph import build_adjacency, build_graph
+    z = np.load(os.path.join(GOLDEN, "graph_7_34.npz"))
+    assert np.abs(build_adjacency(z["coords34"]) - z["A34"]).max() <= 1e-12
+    assert np.abs(build_adjacency(z["coords34"][:7]) - z["A7"]).max() <= 1e-12
+    df = pd.DataFrame({"Station Name": ["s%d" % i for i in range(34)] * 2,
+                       "Latitude": list(z["coords34"][:, 0]) * 2, "Longitude": list(z["coords34"][:, 1]) * 2})
+    assert np.abs(build_graph(df) - z["A34"]).max() <= 1e-12      # duplicates dropped, first-appearance order

@@ -174,3 +174,38 @@ def test_f16x3_tiny_gradients_survive_range_scaling():
     Y.backward(dY.to(dev))
     for k, v in model.named_parameters():
         assert rel_to_max(v.grad.cpu(), go[k]) <= G_TOL, k
+
+
+def test_make_windows_bit_exact_vs_oracle():
+    """N2: on-device window batcher == src/step4_sequence_preparer.py:7-21 (oracle.make_windows), bit for bit."""
+    import numpy as np
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.data import make_windows
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    Ttot, S, seq = 131, 7, 12
+    data = rng.random((Ttot, S, 15)).astype(np.float32)          # 2 id columns + 13 features, as the reference
+    xs, ys = orc.make_windows(data[: (Ttot - 3) // seq * seq + 3], seq)
+    feat = torch.from_numpy(np.ascontiguousarray(data[:, :, 2:15])).to(dev)
+    X, L = make_windows(feat, seq)
+    assert X.shape == xs.shape and L.shape == ys.shape
+    assert torch.equal(X.cpu(), torch.from_numpy(xs)) and torch.equal(L.cpu(), torch.from_numpy(ys))
+    perm = [3, 0, 7, 5]                                            # shuffled windows (:23-26)
+    Xp, Lp = make_windows(feat, seq, starts=[p * seq for p in perm])
+    assert torch.equal(Xp.cpu(), torch.from_numpy(xs[perm])) and torch.equal(Lp.cpu(), torch.from_numpy(ys[perm]))
+    with pytest.raises(RuntimeError):                              # a window whose labels run past the data
+        make_windows(feat, seq, starts=[Ttot - seq - 2])
+
+
+def test_predict_last_matches_reference_readout():
+    """N4: last-timestep, de-normalised read-out of src/main.py:103,116."""
+    from windgnn_amd.data import predict_last
+    dev = _dev()
+    fx = load_fixture("f2_s7_t12_b32_ckpt")
+    model = _model_from(fx["params"], 7, 21)
+    with torch.no_grad():
+        Y = model(torch.from_numpy(fx["A"]).to(dev), torch.from_numpy(fx["X"]).to(dev))
+    wmin, wmax = 0.0, 87.5
+    out = predict_last(Y, wmin, wmax).cpu()
+    ref = torch.from_numpy(fx["Y"])[:, -1, :] * (wmax - wmin) + wmin
+    assert max_abs(out, ref) <= 1e-4 * (wmax - wmin)

@@ -47,6 +47,10 @@ EXPORTS = {
                                      C.c_size_t, C.c_void_p]),
     "wgnn_mse_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wgnn_make_windows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                    C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wgnn_predict_last": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p,
+                                    C.c_void_p]),
     "wgnn_profile_enable": (C.c_int, [C.c_int]),
     "wgnn_profile_read": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
