@@ -26,6 +26,19 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
 BOUND_HBM_PREFIXES = ("mse_", "adam_", "amax_", "splitk_reduce", "split_weight", "gcn_partial")
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.py), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            k = json.load(open(path))["kernels"].get(kernel)
+        except Exception:
+            k = None
+        if k:
+            return {"bytes_per_launch": round(k["bytes_per_launch"]), "source": os.path.basename(path)}
+    return None
+
+
 def adjacency_34():
     z = np.load(os.path.join(ROOT, "tests", "golden", "graph_7_34.npz"))
     return torch.from_numpy(z["A34"]).float()          # src/main.py:26: float64 -> .float()
@@ -148,17 +161,24 @@ def main():
         d = recs[0]
         avg_s = d["ms"] / d["launches"] * 1e-3
         bound = "hbm" if d["name"].startswith(BOUND_HBM_PREFIXES) else "mfma"
+        tr = measured_traffic(d["name"])
         if bound == "mfma":
             ach = d["flops"] / d["launches"] / avg_s / 1e12
             peak = MFMA_PEAK_TFLOPS[args.math]
             roofline = {"kernel": d["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": tr["bytes_per_launch"] if tr else None,
                         "avg_launch_us": round(avg_s * 1e6, 2)}
         else:
             ach = d["bytes"] / d["launches"] / avg_s / 1e9
             roofline = {"kernel": d["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": tr["bytes_per_launch"] if tr else None,
                         "avg_launch_us": round(avg_s * 1e6, 2)}
+        roofline["algorithmic_bytes_per_launch"] = round(d["bytes"] / d["launches"])
+        roofline["hbm_GBs_algorithmic"] = round(d["bytes"] / d["launches"] / avg_s / 1e9, 1)
+        if tr:
+            roofline["traffic_source"] = tr["source"]
         # forward-only timing: north-star "fused forward vs HBM roofline" (52 224 algorithmic B/window)
         from windgnn_amd.functional import gcn_gru_forward_raw
         torch.cuda.synchronize()

@@ -1,0 +1,42 @@
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of `python bench.py` into per-kernel HBM traffic.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcF -- python bench.py --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcW -- python bench.py --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmcF gpurun_out/pmcW > profiles/rN_traffic.json
+
+Per MI355X_MICROARCH.md (HBM / rocprofv3): counters are in KiB; on gfx950 FETCH_SIZE reports exactly half
+of the bytes of a wide coalesced streaming read, so reads are doubled; WRITE_SIZE is exact for 16-B streaming
+stores.  Output: mean bytes per launch for each kernel, keyed by the names bench.py prints."""
+import collections, csv, glob, json, os, re, sys
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)(ILi(\d+)(ELi(\d+))?E)?Ev", n)
+    if m:
+        t = m.group(3)
+        return m.group(1) + ("<%s%s>" % (t, "," + m.group(5) if m.group(5) else "") if t else "")
+    n = n.split("(")[0]
+    return re.sub(r"\s+", "", n)
+
+
+def collect(d, counter):
+    vals = collections.defaultdict(list)
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                vals[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return vals
+
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    f = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else 0.0
+    w = sum(write[k]) / len(write[k]) if write.get(k) else 0.0
+    out[k] = {"read_bytes": 2.0 * f * 1024, "write_bytes": w * 1024, "bytes_per_launch": (2.0 * f + w) * 1024,
+              "launches_seen": max(len(fetch.get(k, [])), len(write.get(k, [])))}
+json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB -> bytes; reads x2 (gfx950 "
+                     "FETCH_SIZE half-count for wide streaming reads, MI355X_MICROARCH.md)", "kernels": out},
+          sys.stdout, indent=1)
