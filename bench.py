@@ -160,7 +160,12 @@ def main():
                     "ms_per_step": round(r["ms"] / args.steps, 4)} for r in recs]
         d = recs[0]
         avg_s = d["ms"] / d["launches"] * 1e-3
-        bound = "hbm" if d["name"].startswith(BOUND_HBM_PREFIXES) else "mfma"
+        # which roofline binds this kernel: time its ALGORITHMIC bytes need at the HBM peak vs the time its
+        # algorithmic flops need at the MFMA peak (f16x3 issues 3 MFMA passes per product => peak / 3)
+        eff_peak = MFMA_PEAK_TFLOPS[args.math] / (3.0 if args.math == "f16x3" else 1.0)
+        t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
+        t_mfma = d["flops"] / (eff_peak * 1e12)
+        bound = "hbm" if (d["name"].startswith(BOUND_HBM_PREFIXES) or t_hbm >= t_mfma) else "mfma"
         tr = measured_traffic(d["name"])
         if bound == "mfma":
             ach = d["flops"] / d["launches"] / avg_s / 1e12

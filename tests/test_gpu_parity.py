@@ -209,3 +209,44 @@ def test_predict_last_matches_reference_readout():
     out = predict_last(Y, wmin, wmax).cpu()
     ref = torch.from_numpy(fx["Y"])[:, -1, :] * (wmax - wmin) + wmin
     assert max_abs(out, ref) <= 1e-4 * (wmax - wmin)
+
+
+def test_full_size_properties_B4096():
+    """BASELINE's full size (S=34, T=24, B=4096, H=102, f16x3): properties that need no oracle run.
+    (a) windows are independent: the big batch equals its two halves run separately, bit for bit;
+    (b) the backward is linear in dY and the range scaling is a power of two: grads(4*dY) == 4*grads(dY) exactly;
+    (c) gradients add over windows: grads(batch) ~= grads(half 1) + grads(half 2);
+    (d) a 256-window slice agrees with the fp64 oracle."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
+    import numpy as np, os
+    from conftest import GOLDEN
+    dev = _dev()
+    S, T, B, H = 34, 24, 4096, 102
+    A = torch.from_numpy(np.load(os.path.join(GOLDEN, "graph_7_34.npz"))["A34"]).float()
+    g = torch.Generator().manual_seed(99)
+    X = torch.rand(B, T, S, 13, generator=g)
+    dY = (torch.rand(B, T, H, generator=g) - 0.5) * 1e-6
+    p = orc.init_params(S, 13, H, seed=3)
+    model = _model_from(p, S, H, "f16x3")
+    params = [q.detach() for q in model.hot_path_parameters()]
+    Ad, Xd, dYd = A.to(dev), X.to(dev), dY.to(dev)
+
+    def run(Xs, dYs):
+        Y, stash, d = gcn_gru_forward_raw(Ad, Xs, params, model.math, want_stash=True)
+        grads = [torch.empty_like(q) for q in params]
+        gcn_gru_backward_raw(d, Ad, Xs, params, Y, dYs, stash, grads)
+        return Y, grads
+
+    Y, G = run(Xd, dYd)
+    Y1, G1 = run(Xd[: B // 2].contiguous(), dYd[: B // 2].contiguous())
+    Y2, G2 = run(Xd[B // 2:].contiguous(), dYd[B // 2:].contiguous())
+    assert torch.equal(Y[: B // 2], Y1) and torch.equal(Y[B // 2:], Y2)                       # (a)
+    _, G4 = run(Xd, (dYd * 4.0).contiguous())
+    for a, b in zip(G, G4):
+        assert torch.equal(a * 4.0, b)                                                        # (b)
+    for a, b, c in zip(G, G1, G2):
+        assert rel_to_max((b + c).cpu(), a.cpu()) <= 1e-5                                      # (c)
+    n = 256
+    Yo, cache = orc.forward(A.double(), X[:n].double(), {k: v.double() for k, v in p.items()})
+    assert max_abs(Y[:n].cpu(), Yo) <= Y_TOL                                                   # (d)
