@@ -11,12 +11,18 @@ import collections, csv, glob, json, os, re, sys
 
 
 def short(n):
+    """rocprofv3 kernel name -> the name bench.py prints (e.g. gcnx_bwd_kernel<3>, pgemm_tn_kernel<5>)."""
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n)
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)(ILi(\d+)(ELi(\d+))?E)?Ev", n)
-    if m:
-        t = m.group(3)
-        return m.group(1) + ("<%s%s>" % (t, "," + m.group(5) if m.group(5) else "") if t else "")
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", n)
+    if m:                                   # Itanium mangling: <len><name>[I Li<k>E ... E]
+        ln = int(m.group(1))
+        rest = n[m.end():]
+        name, tail = rest[:ln], rest[ln:]
+        t = re.match(r"I((?:Li\d+E)+)E", tail)
+        if t:
+            return name + "<" + ",".join(re.findall(r"Li(\d+)E", t.group(1))) + ">"
+        return name
     n = n.split("(")[0]
     return re.sub(r"\s+", "", n)
 

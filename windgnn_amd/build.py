@@ -10,7 +10,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libwindgnn_hip.so")
-SOURCES = ["api.hip", "gcn.hip", "gemm.hip", "gru.hip", "train_ops.hip", "prof.hip", "xgemm.hip", "gcnx.hip", "grux.hip", "pgemm.hip", "data_ops.hip"]
+SOURCES = ["api.hip", "gcn.hip", "gemm.hip", "gru.hip", "train_ops.hip", "prof.hip", "gcnx.hip", "grux.hip", "pgemm.hip", "data_ops.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "windgnn.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -89,16 +89,7 @@ int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* 
                          int ncols_main, float* bias_out, const float* scales /*nullable: *= scales[1]*/,
                          hipStream_t st);
 
-// split-fp16 MFMA GEMMs (xgemm.hip)
-int launch_split_weight(const float* W, int R, int C, int transpose, void* planes, int Rp, int Cp, hipStream_t st);
-int launch_amax_scale(const float* x, int64_t n, float* scales, float* part, hipStream_t st);
-int xgemm_nt_np(int N);   // padded row count of the B planes for N output columns, -1 if unsupported
-// s_in: A is multiplied by s_in[0] while splitting; s_out: C is multiplied by s_out[1] (both nullable)
-int launch_xgemm_nt(const float* A, int lda, int M, int Kp, const void* Bplanes, int Np, float* C, int ldc, int N,
-                    const float* bias, const float* s_in, const float* s_out, hipStream_t st);
-int launch_xgemm_tn(const float* A, int lda, int mcols, const float* B, int ldb, int ncols_b, int ones_col,
-                    int shift_T, int K, int splitk, float* partial, int Mout, int Nout, const float* s_in,
-                    hipStream_t st);
+int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>= 448 floats*/, hipStream_t st);
 // split-fp16 GRU recurrences with register-resident weights (grux.hip)
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)

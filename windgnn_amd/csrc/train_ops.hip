@@ -1,7 +1,8 @@
 // Call-site ops of the reference training step that sit either side of the hot path:
 //   nn.MSELoss()(outputs, batch_y)      src/main.py:49,72   -> loss and dY = 2 (Y-L) scale / n
 //   torch.optim.Adam(lr=1e-3).step()    src/main.py:52,80   -> flat-buffer Adam
-// Both are HBM-bound elementwise passes; float4 where alignment allows.
+//   amax_scale: power-of-two range scale of the f16x3 backward, scales = {2^k, 2^-k} with 2^k*max|dY| in [1,2)
+// All are HBM-bound elementwise passes; float4 where alignment allows.
 #include "common.h"
 
 namespace {
@@ -59,7 +60,54 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
   p[i] -= lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
 }
 
+// scales[0] = 2^-floor(log2(max|x|)) (1 if the max is 0 or not finite), scales[1] = 1/scales[0]
+__global__ void __launch_bounds__(256) amax_partial_kernel(const float* __restrict__ x, int64_t n,
+                                                           float* __restrict__ part) {
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = (((uintptr_t)x & 15) == 0) ? n / 4 : 0;
+  const f32x4* x4 = (const f32x4*)x;
+  for (int64_t i = gid; i < n4; i += stride) {
+    const f32x4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (int64_t i = 4 * n4 + gid; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(ws[0], ws[1]), fmaxf(ws[2], ws[3]));
+}
+
+__global__ void amax_finalize_kernel(const float* __restrict__ part, int nblk, float* scales) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 64) m = fmaxf(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+  if (threadIdx.x == 0) {
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+      s = ldexpf(1.f, 1 - e);        // s*m in [1, 2)
+    }
+    scales[0] = s;
+    scales[1] = 1.f / s;
+  }
+}
+
 }  // namespace
+
+int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=448 floats*/, hipStream_t st) {
+  PROF_LAUNCH("amax_partial_kernel", (double)n, 4.0 * n, st,
+              hipLaunchKernelGGL(amax_partial_kernel, dim3(448), dim3(256), 0, st, x, n, part));
+  WGNN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(64), 0, st, part, 448, scales);
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
 
 int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY, float* loss, float* ws,
                hipStream_t st) {
