@@ -31,14 +31,32 @@ __device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
   c = mfma_x(a.hi, b.hi, c);
   return c;
 }
+// hi = fp16(x) (v_cvt_pk_f16_f32, 2 values per instruction), lo = fp16(x - hi) with the difference
+// formed by v_fma_mix_f32 reading hi straight out of the packed register: 2 VALU per value instead
+// of the 3 hipcc emits for the C expression (these kernels are VALU-issue-bound on exactly this).
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  float t0, t1;
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_cvt_pk_f16_f32 %1, %2, %3\n\t"
+      "s_nop 1"   // VALU write -> MFMA operand read needs 2 wait states; hipcc pads nothing inside/after asm
+      : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1)
+      : "v"(x0), "v"(x1));
+}
 __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
-  Frag f;
+  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v hi, lo;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const _Float16 h = (_Float16)x[j];
-    f.hi[j] = h;
-    f.lo[j] = (_Float16)(x[j] - (float)h);
+  for (int j = 0; j < 4; ++j) {
+    unsigned h, l;
+    split2(x[2 * j], x[2 * j + 1], h, l);
+    hi[j] = h;
+    lo[j] = l;
   }
+  Frag f;
+  f.hi = __builtin_bit_cast(h8, hi);
+  f.lo = __builtin_bit_cast(h8, lo);
   return f;
 }
 __device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, float v) {
