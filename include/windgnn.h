@@ -110,6 +110,15 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
              const float* Y, const float* dY, const void* stash, const wgnn_grads* g,
              void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same backward in two parts, for data-parallel callers that want to overlap the gradient
+ * all-reduce with the rest of the backward (no reference counterpart: it has no collectives):
+ *   part = 1: BPTT + dW_ih, db_ih, dW_hh, db_hh (99.8 % of the gradient bytes) are final on return;
+ *   part = 2: dg and the four conv gradients (needs part 1 to have run on the same workspace);
+ *   part = 3: both (== wgnn_bwd). */
+int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p,
+                  const float* Y, const float* dY, const void* stash, const wgnn_grads* g,
+                  void* workspace, size_t workspace_bytes, void* stream, int part /* 1, 2 or 3 */);
+
 /* One GraphConvLayer: out[n,S,F] = relu(A X[n] W + b) for n = 0..ntiles-1 (ntiles = prod of the
  * leading dims of attr_matrix).  Backward: dW, db (overwritten) and, if dX != NULL, dX. */
 size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F);

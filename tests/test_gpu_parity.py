@@ -250,3 +250,22 @@ def test_full_size_properties_B4096():
     n = 256
     Yo, cache = orc.forward(A.double(), X[:n].double(), {k: v.double() for k, v in p.items()})
     assert max_abs(Y[:n].cpu(), Yo) <= Y_TOL                                                   # (d)
+
+
+def test_backward_in_two_parts_equals_one_call():
+    """wgnn_bwd_part(1) then (2) must give bit-identical gradients to wgnn_bwd (the data-parallel overlap path)."""
+    from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
+    dev = _dev()
+    fx = load_fixture("f3b_s34_t24_b4_rand")
+    model = _model_from(fx["params"], 34, 102, "f16x3")
+    params = [q.detach() for q in model.hot_path_parameters()]
+    A, X = torch.from_numpy(fx["A"]).to(dev), torch.from_numpy(fx["X"]).to(dev)
+    dY = torch.from_numpy(fx["L"]).to(dev) * 1e-3
+    Y, stash, d = gcn_gru_forward_raw(A, X, params, model.math, want_stash=True)
+    g1 = [torch.zeros_like(q) for q in params]
+    g2 = [torch.zeros_like(q) for q in params]
+    gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, g1, part=3)
+    gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, g2, part=1)
+    assert all(torch.equal(a, b) for a, b in zip(g1[4:], g2[4:]))        # GRU gradients final after part 1
+    gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, g2, part=2)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))

@@ -169,6 +169,14 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
 int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
              const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
              void* stream) {
+  return wgnn_bwd_part(d, A, X, p, Y, dY, stash, g, workspace, workspace_bytes, stream, 3);
+}
+
+int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
+                  const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
+                  void* stream, int which) {
+  if (which < 1 || which > 3) return WGNN_ERR_SHAPE;
+  const bool do_gru = which & 1, do_gcn = which & 2;
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
   if (!A || !X || !p || !Y || !dY || !stash || !g || !workspace) return WGNN_ERR_NULL;
@@ -192,13 +200,14 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   if (x3) {
     // Everything downstream of dY is linear in it: run it in units scaled by scales[0] = 2^k (so that
     // fp16 never sees ~1e-9 values) and multiply only the final gradients by scales[1] = 2^-k.
-    rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
-    if (rc != WGNN_OK) return rc;
     _Float16* dGIh = (_Float16*)dGI;
     _Float16* dGHh = (_Float16*)dGH;
     const _Float16* gh = (const _Float16*)gact;
     const _Float16* yph = (const _Float16*)(sf + L.st_yp);
     const size_t PG = L.BT * L.Gp;
+    if (do_gru) {
+    rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
+    if (rc != WGNN_OK) return rc;
     rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;
     // dW_hh | db_hh = dGH^T [Hprev | 1]   (Hprev row (b,t) = Y-plane row (b,t-1), zero at t = 0)
@@ -213,6 +222,8 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     if (rc != WGNN_OK) return rc;
     rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales, st);
     if (rc != WGNN_OK) return rc;
+    }   // the four GRU gradients are final here: a data-parallel caller can start reducing them now
+    if (!do_gcn) return WGNN_OK;
     // dg = dGI W_ih   (B operand = split(W_ih^T) [np_i][Gp]); dg stays in scaled units
     rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, ws + L.ws_planes_b, L.np_i, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;
@@ -226,9 +237,9 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
                                      g->conv2_weight, g->conv2_bias, st);
   }
 
-  rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
-  if (rc != WGNN_OK) return rc;
-  {
+  if (do_gru) {
+    rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
+    if (rc != WGNN_OK) return rc;
     // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
     GemmArgs a = {};
     a.A = dGH; a.lda = (int)L.Gp; a.a_kcontig = 0;
@@ -249,6 +260,9 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     if (rc != WGNN_OK) return rc;
     rc = launch_splitk_reduce(part, L.sk_ih, b.M, b.N, g->w_ih, (int)L.I, (int)L.I, g->b_ih, nullptr, st);
     if (rc != WGNN_OK) return rc;
+  }
+  if (!do_gcn) return WGNN_OK;
+  {
     // dg = dGI W_ih
     GemmArgs c = {};
     c.A = dGI; c.lda = (int)L.Gp; c.a_kcontig = 1;

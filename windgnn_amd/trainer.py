@@ -47,9 +47,20 @@ class TrainStep:
         return loss, Y
 
     def step(self, A, X, L):
-        loss, Y = self.forward_backward(A, X, L)
         if self.world > 1:
-            allreduce_flat_(self.flat_g, self.group)                        # ONE RCCL sum over xGMI
+            # Overlap: the GRU gradients (99.8 % of the bucket) are final after part 1 of the backward, so
+            # their all-reduce runs on RCCL's stream while part 2 (dg GEMM + GCN backward, ~30 % of the
+            # step) still computes; the 364 conv gradients follow in a second, tiny all-reduce.
+            Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True)
+            loss, dY = mse_loss_grad(Y, L, grad_scale=1.0 / self.world)
+            gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views, part=1)
+            n_conv = sum(g.numel() for g in self.g_views[:4])
+            work = torch.distributed.all_reduce(self.flat_g[n_conv:], group=self.group, async_op=True)
+            gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views, part=2)
+            allreduce_flat_(self.flat_g[:n_conv], self.group)
+            work.wait()
+        else:
+            loss, Y = self.forward_backward(A, X, L)
         self.steps += 1
         adam_step_(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.steps, self.lr,
                    self.betas[0], self.betas[1], self.eps)                   # src/main.py:80
