@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 S, T, F, H = 34, 24, 13, 102
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
 # which roofline bounds each kernel (DESIGN.md "Kernels")
 BOUND_HBM_PREFIXES = ("mse_", "adam_", "amax_", "splitk_reduce", "split_weight", "gcn_partial")
 
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="windows per GPU (weak scaling)")
-    ap.add_argument("--math", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--math", default="f16x3", choices=["f32", "f16x3", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -211,7 +211,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.math == "f32" else "f16x3(split-fp32)",
+            "dtype": {"f32": "f32", "f16x3": "f16x3(split-fp32)", "f16": "f16"}[args.math],
             "data": "synthetic",
             "config": {"workload": "S=34 stations, T=24, F=13, H=102, B=%d windows/GPU; step = forward + MSE + "
                                    "backward + grad all-reduce (N>1) + Adam; fp32 I/O" % B,

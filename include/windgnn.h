@@ -51,7 +51,8 @@ typedef enum wgnn_status {
 /* math mode of the contractions (I/O is always fp32) */
 typedef enum wgnn_math {
   WGNN_MATH_F32 = 0,   /* fp32-input MFMA: bitwise an fp32 fmaf chain */
-  WGNN_MATH_F16X3 = 1  /* split-fp16 (hi+lo) MFMA, 3 products, fp32 accumulate: fp32-grade error */
+  WGNN_MATH_F16X3 = 1, /* split-fp16 (hi+lo) MFMA, 3 products, fp32 accumulate: fp32-grade error */
+  WGNN_MATH_F16 = 2    /* plain fp16 operands, one MFMA pass, fp32 accumulate: ~1e-3 error (16-bit config) */
 } wgnn_math;
 
 typedef enum wgnn_adj_format { WGNN_ADJ_DENSE = 0, WGNN_ADJ_CSR = 1 } wgnn_adj_format;

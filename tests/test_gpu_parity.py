@@ -269,3 +269,26 @@ def test_backward_in_two_parts_equals_one_call():
     assert all(torch.equal(a, b) for a, b in zip(g1[4:], g2[4:]))        # GRU gradients final after part 1
     gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, g2, part=2)
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+
+
+# ---- "f16" math mode: plain fp16 operands, one MFMA pass (BASELINE configs[2], the 16-bit configuration).
+# Its own tolerance, never reported as meeting the fp32 bar: fp16 has an 11-bit significand; observed max
+# |Y - reference| is 1e-3 with the trained checkpoints and 8e-3 with N(0,1) random-init conv weights (plain
+# bf16 measures 3e-2 / 7e-2 on the same fixtures); gradients within 5e-2 of their tensor's max.
+F16_Y_TOL = 2e-2
+F16_G_TOL = 5e-2
+
+
+@pytest.mark.parametrize("fixture", ["f2_s7_t12_b32_ckpt", "f3_s34_t24_b4_ckpt", "f3b_s34_t24_b4_rand"])
+def test_f16_mode_within_its_stated_tolerance(fixture):
+    dev = _dev()
+    fx = load_fixture(fixture)
+    S, H = fx["A"].shape[0], fx["Y"].shape[-1]
+    model = _model_from(fx["params"], S, H, "f16")
+    A, X, L = (torch.from_numpy(fx[k]).to(dev) for k in ("A", "X", "L"))
+    out, loss, grads = _run_step(model, A, X, L)
+    ey = max_abs(out.reshape(fx["Y"].shape), fx["Y"])
+    assert ey <= F16_Y_TOL, ey
+    assert ey > 1e-6          # sanity: this really is the 16-bit path, not the split one
+    for k in PARAM_KEYS:
+        assert rel_to_max(grads[k], fx["grads"][k]) <= F16_G_TOL, k

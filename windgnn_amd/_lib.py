@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libwindgnn_hip.so")
 
 MATH_F32 = 0
 MATH_F16X3 = 1
+MATH_F16 = 2
 ADJ_DENSE = 0
 ADJ_CSR = 1
 

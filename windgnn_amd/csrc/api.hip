@@ -29,7 +29,7 @@ int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
 
 Layout make_layout(const wgnn_dims* d) {
   Layout L;
-  const bool x3 = d->math == WGNN_MATH_F16X3;
+  const bool x3 = d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16;   // the fp16-plane kernel family
   L.BT = (size_t)d->B * d->T;
   L.I = (size_t)d->S * d->F;
   L.Ip = rup(L.I + (x3 ? 1 : 0), 32);       // f16x3: room for the ones column at index I
@@ -84,8 +84,8 @@ int check_dims(const wgnn_dims* d) {
   if (d->adj_format != WGNN_ADJ_DENSE) return WGNN_ERR_UNSUPPORTED;
   if (d->S > 64) return WGNN_ERR_UNSUPPORTED;       // dense LDS-resident adjacency path
   if (d->math == WGNN_MATH_F32 && !gru_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
-  if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3) return WGNN_ERR_DTYPE;
-  if (d->math == WGNN_MATH_F16X3 && !grux_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
+  if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3 && d->math != WGNN_MATH_F16) return WGNN_ERR_DTYPE;
+  if (d->math != WGNN_MATH_F32 && !grux_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
   return WGNN_OK;
 }
 
@@ -136,7 +136,8 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   float* GI = ws + L.ws_GI;
   float* g = sf ? sf + L.st_g : ws + L.ws_g;
   float* gates = sf ? sf + L.st_gates : nullptr;
-  const bool x3 = d->math == WGNN_MATH_F16X3;
+  const bool x3 = d->math != WGNN_MATH_F32;          // fp16-plane kernels
+  const bool full = d->math == WGNN_MATH_F16X3;      // three-pass split products (false: one fp16 pass)
 
   if (x3) {
     // W_ih as stage-major fp16 planes [np_g3][Ip] with b_ih folded into column I (g's ones column)
@@ -144,14 +145,14 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
                               (int)L.Ip, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                          (int)L.Ip, st);
+                          (int)L.Ip, full, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
-                         (int)L.Gp, (int)L.G3, nullptr, st);
+                         (int)L.Gp, (int)L.G3, nullptr, full, st);
     if (rc != WGNN_OK) return rc;
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
-                           st);
+                           full, st);
   }
   rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
                        (int)L.Ip, st);
@@ -195,7 +196,8 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
   float* dg = ws + L.ws_dg;
   float* part = ws + L.ws_part;
   float* scales = ws + L.ws_scales;          // [0] = 2^k, [1] = 2^-k (f16x3 range scaling), then 256 partials
-  const bool x3 = d->math == WGNN_MATH_F16X3;
+  const bool x3 = d->math != WGNN_MATH_F32;
+  const bool full = d->math == WGNN_MATH_F16X3;
 
   if (x3) {
     // Everything downstream of dY is linear in it: run it in units scaled by scales[0] = 2^k (so that
@@ -208,17 +210,17 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     if (do_gru) {
     rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
     if (rc != WGNN_OK) return rc;
-    rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, st);
+    rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
     if (rc != WGNN_OK) return rc;
     // dW_hh | db_hh = dGH^T [Hprev | 1]   (Hprev row (b,t) = Y-plane row (b,t-1), zero at t = 0)
     rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT, L.sk_hh, part,
-                         (int)L.G3, (int)L.H + 1, st);
+                         (int)L.G3, (int)L.H + 1, full, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales, st);
     if (rc != WGNN_OK) return rc;
     // dW_ih | db_ih = dGI^T [g | 1]
     rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part,
-                         (int)L.G3, (int)L.I + 1, st);
+                         (int)L.G3, (int)L.I + 1, full, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales, st);
     if (rc != WGNN_OK) return rc;
@@ -228,10 +230,10 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, ws + L.ws_planes_b, L.np_i, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I,
-                         (int)L.I, nullptr, st);
+                         (int)L.I, nullptr, full, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
-                          scales, /*scale_in=*/0, ws + L.ws_gcnpart, st);
+                          scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, st);
     if (rc != WGNN_OK) return rc;
     return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT), g->conv1_weight, g->conv1_bias,
                                      g->conv2_weight, g->conv2_bias, st);

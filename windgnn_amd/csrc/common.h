@@ -94,9 +94,9 @@ int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                    float* gates, void* y_planes, hipStream_t st);
+                    float* gates, void* y_planes, bool x3, hipStream_t st);
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
-                    const float* scales, void* dGI_planes, void* dGH_planes, int ldd, hipStream_t st);
+                    const float* scales, void* dGI_planes, void* dGH_planes, int ldd, bool x3, hipStream_t st);
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,
                     const float* b1, const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
@@ -112,18 +112,18 @@ size_t gcnx2_bwd_partial_floats(int ntiles);
 int gcnx_bwd_grid(int ntiles);
 // g_planes: fp16 hi plane [ntiles][ldg] followed by the lo plane; column S*13 holds 1.0, later columns 0
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, void* g_planes, int ldg, hipStream_t st);
+                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, hipStream_t st);
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
-                     int scale_in, float* partial, hipStream_t st);
+                     int scale_in, float* partial, bool x3, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
                          int Rp, int Cp, hipStream_t st);
 int pgemm_nt_np(int N);
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                    int ldc, int N, const float* s_out, hipStream_t st);
+                    int ldc, int N, const float* s_out, bool x3, hipStream_t st);
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
-                    int K, int splitk, float* partial, int Mout, int Nout, hipStream_t st);
+                    int K, int splitk, float* partial, int Mout, int Nout, bool x3, hipStream_t st);
 int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W,
                     const float* b, float* out, hipStream_t st);
 size_t gcn1_bwd_partial_floats(int ntiles);

@@ -33,9 +33,14 @@ struct Frag { h8 hi, lo; };
 __device__ __forceinline__ f32x4 mfma_x(h8 a, h8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// X3 = true: split-fp16 product lo*hi + hi*lo + hi*hi (fp32-grade); X3 = false: plain fp16 operands, one pass
+// (the "f16" math mode for BASELINE's 16-bit configuration; lo halves are never formed).
+template <bool X3>
 __device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
-  c = mfma_x(a.lo, b.hi, c);
-  c = mfma_x(a.hi, b.lo, c);
+  if (X3) {
+    c = mfma_x(a.lo, b.hi, c);
+    c = mfma_x(a.hi, b.lo, c);
+  }
   c = mfma_x(a.hi, b.hi, c);
   return c;
 }
@@ -52,13 +57,21 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
       : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1)
       : "v"(x0), "v"(x1));
 }
+__device__ __forceinline__ void cvt2(float x0, float x1, unsigned& hi) {
+  asm("v_cvt_pk_f16_f32 %0, %1, %2\n\t"
+      "s_nop 1"
+      : "=v"(hi)
+      : "v"(x0), "v"(x1));
+}
+template <bool X3>
 __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
   typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-  u32x4v hi, lo;
+  u32x4v hi, lo = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    unsigned h, l;
-    split2(x[2 * j], x[2 * j + 1], h, l);
+    unsigned h, l = 0u;
+    if (X3) split2(x[2 * j], x[2 * j + 1], h, l);
+    else cvt2(x[2 * j], x[2 * j + 1], h);
     hi[j] = h;
     lo[j] = l;
   }
@@ -68,14 +81,15 @@ __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
   return f;
 }
 // operand fragment from two stacked accumulator row-tiles (slots j<4 from t0, j>=4 from t1)
+template <bool X3>
 __device__ __forceinline__ Frag frag_of(f32x4 t0, f32x4 t1) {
   const float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-  return split_vals(x);
+  return split_vals<X3>(x);
 }
 __device__ __forceinline__ int rho(int ks, int g, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3); }
 
 // "A [m = s][k = s']" fragments in rho order (also the B operand of any product with A^T)
-template <int NT, int KS, bool TRANSPOSE>
+template <int NT, int KS, bool TRANSPOSE, bool X3>
 __device__ __forceinline__ void build_A_frags(Frag (&CA)[NT][KS], const float* __restrict__ A, int S, int c, int g) {
 #pragma unroll
   for (int mi = 0; mi < NT; ++mi)
@@ -89,7 +103,7 @@ __device__ __forceinline__ void build_A_frags(Frag (&CA)[NT][KS], const float* _
         if (m < S && k < S) v = TRANSPOSE ? A[k * S + m] : A[m * S + k];
         x[j] = v;
       }
-      CA[mi][ks] = split_vals(x);
+      CA[mi][ks] = split_vals<X3>(x);
     }
 }
 
@@ -150,16 +164,17 @@ __device__ __forceinline__ void gload_pairs_h(h2 (&r)[NP], const _Float16* __res
 }
 
 // A-operand fragment (natural k = f) of X rows 16i + c from the staged tile
+template <bool X3>
 __device__ __forceinline__ Frag xfrag_nat(const float* xb, int i, int c, int g) {
   const f32x4 v0 = *(const f32x4*)(xb + (16 * i + c) * XS + 8 * (g & 1));
   const f32x4 v1 = *(const f32x4*)(xb + (16 * i + c) * XS + 8 * (g & 1) + 4);
   const bool on = g < 2;                       // k = 8g + j >= 16 for g >= 2: zero
   const float x[8] = {on ? v0[0] : 0.f, on ? v0[1] : 0.f, on ? v0[2] : 0.f, on ? v0[3] : 0.f,
                       on ? v1[0] : 0.f, on ? v1[1] : 0.f, on ? v1[2] : 0.f, on ? v1[3] : 0.f};
-  return split_vals(x);
+  return split_vals<X3>(x);
 }
 
-template <int NT>
+template <int NT, bool X3>
 __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
@@ -177,7 +192,7 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
   for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;   // pads (f >= 13, s >= S) stay zero forever
 
   Frag CA[NT][KS];
-  build_A_frags<NT, KS, false>(CA, A, S, c, g);
+  build_A_frags<NT, KS, false, X3>(CA, A, S, c, g);
   Frag FW1, FW2;
   float bb1[4], bb2[4];
   {
@@ -189,8 +204,8 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
       const int f2 = 4 * g + j;                      // rho order over one 16-row tile for H1 W2
       x2[j] = (j < 4 && f2 < F13 && c < F13) ? W2[f2 * F13 + c] : 0.f;
     }
-    FW1 = split_vals(x1);
-    FW2 = split_vals(x2);
+    FW1 = split_vals<X3>(x1);
+    FW2 = split_vals<X3>(x2);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = 4 * g + r;
@@ -226,28 +241,28 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
 
     f32x4 U[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) U[i] = mfma3(xfrag_nat(xb, i, c, g), FW1, zero4);   // U1 row-tile i
+    for (int i = 0; i < NT; ++i) U[i] = mfma3<X3>(xfrag_nat<X3>(xb, i, c, g), FW1, zero4);   // U1 row-tile i
     Frag UF[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of<X3>(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
     f32x4 Ht[NT];                                    // H1^T column-tile n: [f][s = 16n + c]
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       f32x4 acc = zero4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3(UF[ks], CA[n][ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], CA[n][ks], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) Ht[n][r] = fmaxf(acc[r] + bb1[r], 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) U[i] = mfma3(frag_of(Ht[i], zero4), FW2, zero4);   // U2 row-tile i [s][f']
+    for (int i = 0; i < NT; ++i) U[i] = mfma3<X3>(frag_of<X3>(Ht[i], zero4), FW2, zero4);   // U2 row-tile i [s][f']
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of<X3>(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       f32x4 acc = zero4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3(UF[ks], CA[n][ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], CA[n][ks], acc);
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bb2[r], 0.f);
@@ -273,7 +288,7 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
           lo[0] = (_Float16)(v0 - (float)hi[0]); lo[1] = (_Float16)(v1 - (float)hi[1]);
           if (p < ldp / 2) {
             dh[p] = __builtin_bit_cast(unsigned, hi);
-            dl[p] = __builtin_bit_cast(unsigned, lo);
+            if (X3) dl[p] = __builtin_bit_cast(unsigned, lo);
           }
         }
       }
@@ -291,7 +306,7 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
 // read in C layout).  A and A^T fragments live in LDS (shared by the 4 waves); dg is scaled by the
 // power of two scales[0] so fp16 never sees ~1e-9 values and the partial sums are un-scaled by
 // scales[1] at the end.
-template <int NT>
+template <int NT, bool X3>
 __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
@@ -313,7 +328,7 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
   for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;
   if (wave == 0) {
     Frag T[NT][KS];
-    build_A_frags<NT, KS, false>(T, A, S, c, g);
+    build_A_frags<NT, KS, false, X3>(T, A, S, c, g);
 #pragma unroll
     for (int mi = 0; mi < NT; ++mi)
 #pragma unroll
@@ -323,7 +338,7 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
       }
   } else if (wave == 1) {
     Frag T[NT][KS];
-    build_A_frags<NT, KS, true>(T, A, S, c, g);
+    build_A_frags<NT, KS, true, X3>(T, A, S, c, g);
 #pragma unroll
     for (int mi = 0; mi < NT; ++mi)
 #pragma unroll
@@ -356,8 +371,8 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
       const int fp = 4 * g + j;                      // k = f' (rho order, one tile), n = c = f: W2^T[f'][f]
       x2[j] = (j < 4 && fp < F13 && c < F13) ? W2[c * F13 + fp] : 0.f;
     }
-    FW1 = split_vals(x1);
-    FW2T = split_vals(x2);
+    FW1 = split_vals<X3>(x1);
+    FW2T = split_vals<X3>(x2);
   }
   const float bias1 = c < F13 ? b1[c] : 0.f;         // H1 is [s][f] here: bias per column
   const float s_in = (scales && scale_in) ? scales[0] : 1.f, s_out = scales ? scales[1] : 1.f;
@@ -400,16 +415,16 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
     // ---- recompute U1, H1 [s][f]
     f32x4 U[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) U[i] = mfma3(xfrag_nat(xb, i, c, g), FW1, zero4);
+    for (int i = 0; i < NT; ++i) U[i] = mfma3<X3>(xfrag_nat<X3>(xb, i, c, g), FW1, zero4);
     Frag UF[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of<X3>(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
     f32x4 H1[NT];
 #pragma unroll
     for (int mi = 0; mi < NT; ++mi) {
       f32x4 acc = zero4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3(ldA(mi, ks), UF[ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(ldA(mi, ks), UF[ks], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s = 16 * mi + 4 * g + r;
@@ -428,29 +443,29 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
       }
     Frag DZF[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) DZF[ks] = frag_of(dZ[2 * ks], (2 * ks + 1 < NT) ? dZ[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) DZF[ks] = frag_of<X3>(dZ[2 * ks], (2 * ks + 1 < NT) ? dZ[2 * ks + 1] : zero4);
     // ---- dU2 [s'][f'] = A^T dZ2 ; dW2 += H1^T dU2
     f32x4 dU[NT];
 #pragma unroll
     for (int mi = 0; mi < NT; ++mi) {
       f32x4 acc = zero4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3(ldT(mi, ks), DZF[ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(ldT(mi, ks), DZF[ks], acc);
       dU[mi] = acc;
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const f32x4 h1 = (2 * ks + 1 < NT) ? H1[2 * ks + 1] : zero4;
       const f32x4 d1 = (2 * ks + 1 < NT) ? dU[2 * ks + 1] : zero4;
-      dW2acc = mfma3(frag_of(H1[2 * ks], h1), frag_of(dU[2 * ks], d1), dW2acc);
+      dW2acc = mfma3<X3>(frag_of<X3>(H1[2 * ks], h1), frag_of<X3>(dU[2 * ks], d1), dW2acc);
     }
     // ---- dU2t [f'][s'] = dZ2^T A ; dH1 [s'][f] = dU2 W2^T ; dZ1 = dH1 * (H1 > 0)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       f32x4 acc = zero4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3(DZF[ks], ldT(n, ks), acc);
-      const f32x4 dh = mfma3(frag_of(acc, zero4), FW2T, zero4);
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(DZF[ks], ldT(n, ks), acc);
+      const f32x4 dh = mfma3<X3>(frag_of<X3>(acc, zero4), FW2T, zero4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = H1[n][r] > 0.f ? dh[r] : 0.f;
@@ -459,13 +474,13 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
       }
     }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) DZF[ks] = frag_of(dZ[2 * ks], (2 * ks + 1 < NT) ? dZ[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) DZF[ks] = frag_of<X3>(dZ[2 * ks], (2 * ks + 1 < NT) ? dZ[2 * ks + 1] : zero4);
     // ---- dU1 = A^T dZ1 ; dW1 += X^T dU1 (X read from the staged tile in C layout [s'][f])
 #pragma unroll
     for (int mi = 0; mi < NT; ++mi) {
       f32x4 acc = zero4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3(ldT(mi, ks), DZF[ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(ldT(mi, ks), DZF[ks], acc);
       dU[mi] = acc;
     }
     f32x4 XC[NT];
@@ -477,7 +492,7 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
     for (int ks = 0; ks < KS; ++ks) {
       const f32x4 x1 = (2 * ks + 1 < NT) ? XC[2 * ks + 1] : zero4;
       const f32x4 d1 = (2 * ks + 1 < NT) ? dU[2 * ks + 1] : zero4;
-      dW1acc = mfma3(frag_of(XC[2 * ks], x1), frag_of(dU[2 * ks], d1), dW1acc);
+      dW1acc = mfma3<X3>(frag_of<X3>(XC[2 * ks], x1), frag_of<X3>(dU[2 * ks], d1), dW1acc);
     }
   }
 
@@ -515,15 +530,21 @@ size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)grid_x(ntiles) * PA
 int gcnx_bwd_grid(int ntiles) { return grid_x(ntiles); }
 
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, void* g_planes, int ldg, hipStream_t st) {
+                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, hipStream_t st) {
   _Float16* ghi = (_Float16*)g_planes;
   _Float16* glo = ghi + (size_t)ntiles * ldg;
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
   const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
   const dim3 grid(grid_x(ntiles));
 #define FWD_CASE(NT)                                                                                              \
-  PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                             \
-              hipLaunchKernelGGL(gcnx_fwd_kernel<NT>, grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, b2, ghi, glo, ldg))
+  if (x3)                                                                                                         \
+    PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                           \
+                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, true>), grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, b2, \
+                                   ghi, glo, ldg));                                                               \
+  else                                                                                                            \
+    PROF_LAUNCH("gcnx_fwd_kernel<" #NT ",f16>", fl, by * 0.75, st,                                                \
+                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, false>), grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, \
+                                   b2, ghi, glo, ldg))
   switch ((S + 15) / 16) {
     case 1: FWD_CASE(1); break;
     case 2: FWD_CASE(2); break;
@@ -538,15 +559,20 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const fl
 
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
-                     int scale_in, float* partial, hipStream_t st) {
+                     int scale_in, float* partial, bool x3, hipStream_t st) {
   const _Float16* g = (const _Float16*)g_planes;   // hi plane carries the sign: g > 0 <=> hi > 0
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
   const dim3 grid(grid_x(ntiles));
 #define BWD_CASE(NT)                                                                                               \
-  PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                              \
-              hipLaunchKernelGGL(gcnx_bwd_kernel<NT>, grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, g, ldg, dg, \
-                                 scales, scale_in, partial))
+  if (x3)                                                                                                          \
+    PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                            \
+                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, g,  \
+                                   ldg, dg, scales, scale_in, partial));                                           \
+  else                                                                                                             \
+    PROF_LAUNCH("gcnx_bwd_kernel<" #NT ",f16>", fl, by, st,                                                        \
+                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, g, \
+                                   ldg, dg, scales, scale_in, partial))
   switch ((S + 15) / 16) {
     case 1: BWD_CASE(1); break;
     case 2: BWD_CASE(2); break;

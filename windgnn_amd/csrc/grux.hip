@@ -25,9 +25,13 @@ struct Frag { h8 hi, lo; };
 __device__ __forceinline__ f32x4 mfma_x(h8 a, h8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// X3: split-fp16 three-pass product; !X3: plain fp16 operands, one pass ("f16" math mode)
+template <bool X3>
 __device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
-  c = mfma_x(a.lo, b.hi, c);
-  c = mfma_x(a.hi, b.lo, c);
+  if (X3) {
+    c = mfma_x(a.lo, b.hi, c);
+    c = mfma_x(a.hi, b.lo, c);
+  }
   c = mfma_x(a.hi, b.hi, c);
   return c;
 }
@@ -44,7 +48,7 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
       : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1)
       : "v"(x0), "v"(x1));
 }
-__device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
+__device__ __forceinline__ Frag split_vals(const float (&x)[8]) {   // weights: once per launch, both halves
   typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
   u32x4v hi, lo;
 #pragma unroll
@@ -59,14 +63,15 @@ __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
   f.lo = __builtin_bit_cast(h8, lo);
   return f;
 }
+template <bool X3>
 __device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, float v) {
   const _Float16 h = (_Float16)v;
   hi[idx] = h;
-  lo[idx] = (_Float16)(v - (float)h);
+  if (X3) lo[idx] = (_Float16)(v - (float)h);
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int KS>   // K steps of 32 over the hidden index (+ the ones column): KS = ceil((H+1)/32)
+template <int KS, bool X3>   // K steps of 32 over the hidden index (+ the ones column): KS = ceil((H+1)/32)
 __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const float* __restrict__ GI, int ldgi,
                                                             const float* __restrict__ Whh,
                                                             const float* __restrict__ bhh, float* __restrict__ Y,
@@ -146,10 +151,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       for (int ks = 0; ks < KS; ++ks) {
         Frag a;
         a.hi = *(const h8*)(hhi + c * HS + 32 * ks + 8 * g);
-        a.lo = *(const h8*)(hlo + c * HS + 32 * ks + 8 * g);
-        ar = mfma3(a, WB[0][ks], ar);
-        az = mfma3(a, WB[1][ks], az);
-        an = mfma3(a, WB[2][ks], an);
+        if (X3) a.lo = *(const h8*)(hlo + c * HS + 32 * ks + 8 * g);
+        else a.lo = a.hi;
+        ar = mfma3<X3>(a, WB[0][ks], ar);
+        az = mfma3<X3>(a, WB[1][ks], az);
+        an = mfma3<X3>(a, WB[2][ks], an);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -174,11 +180,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     __syncthreads();                               // every wave has read h_{t-1}
     if (active && jv) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) put_split(hhi, hlo, (4 * g + r) * HS + j, hnew[r]);
+      for (int r = 0; r < 4; ++r) put_split<X3>(hhi, hlo, (4 * g + r) * HS + j, hnew[r]);
     }
     __syncthreads();
     if (yp_hi) {   // h_t as fp16 planes (the B operand of the dW_hh GEMM): 16-byte chunks straight from LDS
-      for (int q = threadIdx.x; q < 2 * MB * (HP / 8); q += NTHREADS) {
+      for (int q = threadIdx.x; q < (X3 ? 2 : 1) * MB * (HP / 8); q += NTHREADS) {
         const int plane = q / (MB * (HP / 8)), rem = q % (MB * (HP / 8));
         const int m = rem / (HP / 8), ch = rem % (HP / 8);
         const int b = b0 + m;
@@ -200,7 +206,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
 //   dn = dh (1-z), dz = dh (hprev - n), dnt = dn (1-n^2), dr = dnt gh_n,
 //   dar = dr r (1-r), daz = dz z (1-z);  dgi = [dar, daz, dnt], dgh = [dar, daz, dnt r]
 //   dh_next = dh z + dgh W_hh
-template <int KS3>   // K steps of 32 over the 3H gate rows
+template <int KS3, bool X3>   // K steps of 32 over the 3H gate rows
 __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
                                                             const float* __restrict__ Y, const float* __restrict__ dY,
                                                             const float* __restrict__ gates,
@@ -285,14 +291,16 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
         const float dnr = dnt * rg;
         acc[r] = dh * zg;
         if (jv) {
-          put_split(dhi, dlo, m * DS + j, dar);
-          put_split(dhi, dlo, m * DS + H + j, daz);
-          put_split(dhi, dlo, m * DS + 2 * H + j, dnr);
+          put_split<X3>(dhi, dlo, m * DS + j, dar);
+          put_split<X3>(dhi, dlo, m * DS + H + j, daz);
+          put_split<X3>(dhi, dlo, m * DS + 2 * H + j, dnr);
           ihi[m * DS + j] = dhi[m * DS + j];
-          ilo[m * DS + j] = dlo[m * DS + j];
           ihi[m * DS + H + j] = dhi[m * DS + H + j];
-          ilo[m * DS + H + j] = dlo[m * DS + H + j];
-          put_split(ihi, ilo, m * DS + 2 * H + j, dnt);
+          if (X3) {
+            ilo[m * DS + j] = dlo[m * DS + j];
+            ilo[m * DS + H + j] = dlo[m * DS + H + j];
+          }
+          put_split<X3>(ihi, ilo, m * DS + 2 * H + j, dnt);
         }
       }
     }
@@ -303,7 +311,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
         const int buf = q / (MB * cpr), rem = q % (MB * cpr);
         const int m = rem / cpr, ch = rem % cpr;
         const int b = b0 + m;
-        if (b < B) {
+        if (b < B && (X3 || (buf & 1) == 0)) {        // f16 mode: hi planes only
           const h8 v = *(const h8*)(dbuf + (size_t)buf * MB * DS + m * DS + 8 * ch);
           _Float16* dst = buf == 0 ? dGH_hi : (buf == 1 ? dGH_lo : (buf == 2 ? dGI_hi : dGI_lo));
           *(h8*)(dst + ((size_t)b * T + t) * ldd + 8 * ch) = v;
@@ -315,8 +323,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
       for (int ks = 0; ks < KS3; ++ks) {
         Frag a;
         a.hi = *(const h8*)(dhi + c * DS + 32 * ks + 8 * g);
-        a.lo = *(const h8*)(dlo + c * DS + 32 * ks + 8 * g);
-        acc = mfma3(a, WT[ks], acc);
+        if (X3) a.lo = *(const h8*)(dlo + c * DS + 32 * ks + 8 * g);
+        else a.lo = a.hi;
+        acc = mfma3<X3>(a, WT[ks], acc);
       }
     }
     dhn = acc;
@@ -332,15 +341,21 @@ bool grux_shape_supported(int H) { return H >= 1 && H <= 127; }
 int grux_hp(int H) { return 32 * cdiv_i(H + 1, 32); }
 
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                    float* gates, void* y_planes /*nullable: 2 x [B*T][grux_hp(H)] halfs*/, hipStream_t st) {
+                    float* gates, void* y_planes /*nullable: 2 x [B*T+1][grux_hp(H)] halfs*/, bool x3, hipStream_t st) {
   _Float16* yh = (_Float16*)y_planes;
   _Float16* yl = yh ? yh + ((size_t)B * T + 1) * grux_hp(H) : nullptr;   // each plane has B*T + 1 rows
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0));
   const dim3 grid(cdiv_i(B, MB));
 #define FCASE(K)                                                                                                   \
-  PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                               \
-              hipLaunchKernelGGL(grux_fwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, Y, gates, yh, yl))
+  if (x3)                                                                                                          \
+    PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                             \
+                hipLaunchKernelGGL((grux_fwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, \
+                                   Y, gates, yh, yl));                                                             \
+  else                                                                                                             \
+    PROF_LAUNCH("grux_fwd_kernel<" #K ",f16>", fl, by, st,                                                         \
+                hipLaunchKernelGGL((grux_fwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh,    \
+                                   bhh, Y, gates, yh, yl))
   switch (cdiv_i(H + 1, 32)) {
     case 1: FCASE(1); break;
     case 2: FCASE(2); break;
@@ -354,7 +369,7 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
 }
 
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
-                    const float* scales, void* dGI_planes, void* dGH_planes, int ldd, hipStream_t st) {
+                    const float* scales, void* dGI_planes, void* dGH_planes, int ldd, bool x3, hipStream_t st) {
   _Float16* ih = (_Float16*)dGI_planes;
   _Float16* il = ih + (size_t)B * T * ldd;
   _Float16* hh = (_Float16*)dGH_planes;
@@ -364,9 +379,14 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const
   const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (4 * H + 2 * H + 6 * H);
   const dim3 grid(cdiv_i(B, MB));
 #define BCASE(K)                                                                                                   \
-  PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                               \
-              hipLaunchKernelGGL(grux_bwd_kernel<K>, grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, gates, scales, \
-                                 ih, il, hh, hl, ldd))
+  if (x3)                                                                                                          \
+    PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                             \
+                hipLaunchKernelGGL((grux_bwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, gates, \
+                                   scales, ih, il, hh, hl, ldd));                                                  \
+  else                                                                                                             \
+    PROF_LAUNCH("grux_bwd_kernel<" #K ",f16>", fl, by * 0.75, st,                                                  \
+                hipLaunchKernelGGL((grux_bwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, gates, \
+                                   scales, ih, il, hh, hl, ldd))
   switch (cdiv_i(3 * H, 32)) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;

@@ -36,7 +36,7 @@ __device__ __forceinline__ f32x16 mfma_h(h8 a, h8 b, f32x16 c) {
 
 // ------------------------------------------------------------------------------------------------
 // NT.  BM = 128 (wave w owns rows 32w..32w+31), BN = 32*NT_W columns (one N slice per block).
-template <int NT_W>
+template <int NT_W, bool X3>
 __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restrict__ Ahi,
                                                          const _Float16* __restrict__ Alo, int lda, int M, int Kp,
                                                          const _Float16* __restrict__ Bpl, int Np,
@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
   // ds_write of the OLD ones, so loads never overlapped the MFMAs).  One wave-instruction moves a
   // 1 KB "piece" = 16 tile rows x 64 B; the LDS image is lane-linear, so the XOR swizzle the fragment
   // reads expect is applied to the SOURCE chunk index: LDS (row, pos) <- global chunk pos ^ ((row>>2)&3).
-  constexpr int APIECES = 2 * BM / 16, BPIECES = 2 * BN / 16;          // per stage
+  constexpr int PL = X3 ? 2 : 1;                                        // planes moved: hi (+ lo)
+  constexpr int APIECES = PL * BM / 16, BPIECES = PL * BN / 16;        // per stage
   constexpr int NPA = APIECES / 4, NPB = (BPIECES + 3) / 4;            // per wave
   const int prow = lane >> 2, ppos = lane & 3;
   const _Float16* a_src[NPA];
@@ -117,14 +118,17 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
       const int c = 2 * ks + lh;
       const int aoff = sw_off(32 * wave + li, c);
       const h8 ah = *(const h8*)(Ah + aoff);
-      const h8 al = *(const h8*)(Al + aoff);
+      h8 al = ah;
+      if (X3) al = *(const h8*)(Al + aoff);
 #pragma unroll
       for (int j = 0; j < NT_W; ++j) {
         const int boff = sw_off(32 * j + li, c);
         const h8 bh = *(const h8*)(Bh + boff);
-        const h8 bl = *(const h8*)(Bl + boff);
-        acc[j] = mfma_h(al, bh, acc[j]);
-        acc[j] = mfma_h(ah, bl, acc[j]);
+        if (X3) {
+          const h8 bl = *(const h8*)(Bl + boff);
+          acc[j] = mfma_h(al, bh, acc[j]);
+          acc[j] = mfma_h(ah, bl, acc[j]);
+        }
         acc[j] = mfma_h(ah, bh, acc[j]);
       }
     }
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
   // DMA are in flight per workgroup (the kernel is bound by memory latency x bytes in flight, not by
   // issue).  vmcnt is counted: (RING-2) stages * (NPA+NPB) DMA instructions may stay outstanding.
   constexpr int PER = NPA + NPB;
-  static_assert(BPIECES % 4 == 0, "every wave must issue the same number of DMA instructions per stage");
+  static_assert(RING == 2 || BPIECES % 4 == 0, "counted vmcnt needs the same DMA count in every wave");
 #pragma unroll
   for (int s0 = 0; s0 < RING - 1; ++s0)
     if (s0 < nk) dma_stage(smem + s0 * STAGE, s0);
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
 // TN.  BM = 32*MT_W columns of A (every wave), BN = 128 columns of B (wave w owns 32w..32w+31).
 // grid = (splitk, nMblocks * nNblocks): blocks with the same z and different tiles differ by a
 // multiple of splitk in linear id; splitk is a multiple of 8, so they share an XCD's L2.
-template <int MT_W>
+template <int MT_W, bool X3>
 __global__ void __launch_bounds__(PT, 2) pgemm_tn_kernel(const _Float16* __restrict__ Ahi,
                                                          const _Float16* __restrict__ Alo, int lda,
                                                          const _Float16* __restrict__ Bhi,
@@ -177,7 +181,8 @@ __global__ void __launch_bounds__(PT, 2) pgemm_tn_kernel(const _Float16* __restr
   constexpr int RS = 320;                                   // LDS row stride in bytes (== 64 mod 256)
   constexpr int ACH = BM / 8, BCH = BN / 8;                 // 16-byte chunks per tile row
   constexpr int PLANE = 32 * RS, STAGE = 4 * PLANE;         // Ahi, Alo, Bhi, Blo
-  constexpr int NA = (2 * 32 * ACH + PT - 1) / PT, NB = (2 * 32 * BCH + PT - 1) / PT;
+  constexpr int PL = X3 ? 2 : 1;                           // planes staged: hi (+ lo)
+  constexpr int NA = (PL * 32 * ACH + PT - 1) / PT, NB = (PL * 32 * BCH + PT - 1) / PT;
   static_assert(BM * 2 <= RS && BN * 2 <= RS, "tile rows must fit the LDS row stride");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -198,7 +203,7 @@ __global__ void __launch_bounds__(PT, 2) pgemm_tn_kernel(const _Float16* __restr
 #pragma unroll
   for (int it = 0; it < NA; ++it) {
     const int q = tid + PT * it;
-    a_on[it] = q < 2 * 32 * ACH;
+    a_on[it] = q < PL * 32 * ACH;
     const int qq = a_on[it] ? q : 0;
     const int plane = qq / (32 * ACH), rem = qq % (32 * ACH);
     a_lo[it] = plane != 0;
@@ -212,7 +217,7 @@ __global__ void __launch_bounds__(PT, 2) pgemm_tn_kernel(const _Float16* __restr
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
     const int q = tid + PT * it;
-    b_on[it] = q < 2 * 32 * BCH;
+    b_on[it] = q < PL * 32 * BCH;
     const int qq = b_on[it] ? q : 0;
     const int plane = qq / (32 * BCH), rem = qq % (32 * BCH);
     b_lo[it] = plane != 0;
@@ -243,8 +248,8 @@ __global__ void __launch_bounds__(PT, 2) pgemm_tn_kernel(const _Float16* __restr
   } while (0)
 #define TN_STORE(st)                                                                                 \
   do {                                                                                               \
-    _Pragma("unroll") for (int it = 0; it < NA; ++it) if (tid + PT * it < 2 * 32 * ACH) *(u32x4*)((st) + a_dst[it]) = ra[it]; \
-    _Pragma("unroll") for (int it = 0; it < NB; ++it) if (tid + PT * it < 2 * 32 * BCH) *(u32x4*)((st) + b_dst[it]) = rb[it]; \
+    _Pragma("unroll") for (int it = 0; it < NA; ++it) if (tid + PT * it < PL * 32 * ACH) *(u32x4*)((st) + a_dst[it]) = ra[it]; \
+    _Pragma("unroll") for (int it = 0; it < NB; ++it) if (tid + PT * it < PL * 32 * BCH) *(u32x4*)((st) + b_dst[it]) = rb[it]; \
   } while (0)
 
   const int nk = (kend - kbeg + 31) / 32;
@@ -275,13 +280,16 @@ __global__ void __launch_bounds__(PT, 2) pgemm_tn_kernel(const _Float16* __restr
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const h8 bh = trread(cur + 2 * PLANE, 16 * ks, 32 * wave);
-      const h8 bl = trread(cur + 3 * PLANE, 16 * ks, 32 * wave);
+      h8 bl = bh;
+      if (X3) bl = trread(cur + 3 * PLANE, 16 * ks, 32 * wave);
 #pragma unroll
       for (int i = 0; i < MT_W; ++i) {
         const h8 ah = trread(cur, 16 * ks, 32 * i);
-        const h8 al = trread(cur + PLANE, 16 * ks, 32 * i);
-        acc[i] = mfma_h(al, bh, acc[i]);
-        acc[i] = mfma_h(ah, bl, acc[i]);
+        if (X3) {
+          const h8 al = trread(cur + PLANE, 16 * ks, 32 * i);
+          acc[i] = mfma_h(al, bh, acc[i]);
+          acc[i] = mfma_h(ah, bl, acc[i]);
+        }
         acc[i] = mfma_h(ah, bh, acc[i]);
       }
     }
@@ -343,20 +351,28 @@ int pgemm_nt_np(int N) { return cdiv_i(N, 160) * 160; }
 
 // C[M][N] = s_out * A B^T.  A planes [M][lda] (Kp <= lda), B stage-major planes with Np = pgemm_nt_np(N) rows.
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                    int ldc, int N, const float* s_out, hipStream_t st) {
+                    int ldc, int N, const float* s_out, bool x3, hipStream_t st) {
   if (Kp % 32 != 0 || lda % 8 != 0 || Np % 160 != 0) return WGNN_ERR_SHAPE;
   constexpr int NTW = 5;
   static const int dbg = getenv("WGNN_DBG_NT") ? atoi(getenv("WGNN_DBG_NT")) : 0;   // timing ablations only
   const int nm = cdiv_i(M, 128), nslices = Np / 160;
   const int grid = cdiv_i(nm, 8) * 8 * nslices;
   const size_t smem = 2 * (size_t)(2 * 128 + 2 * 32 * NTW) * 64;
-  static std::atomic<unsigned long long> done{0};
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<NTW>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  const double fl = 2.0 * M * (double)N * Kp, by = 4.0 * ((double)M * Kp + (double)M * N) + 4.0 * Np * Kp;
-  PROF_LAUNCH("pgemm_nt_kernel<5>", fl, by, st,
-              hipLaunchKernelGGL(pgemm_nt_kernel<NTW>, dim3(grid), dim3(PT), smem, st, (const _Float16*)Ahi,
-                                 (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, C, ldc, N, s_out, nm,
-                                 nslices, dbg));
+  static std::atomic<unsigned long long> done{0}, done16{0};
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<NTW, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<NTW, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
+  const double fl = 2.0 * M * (double)N * Kp;
+  const double by = (x3 ? 4.0 : 2.0) * ((double)M * Kp + (double)Np * Kp) + 4.0 * (double)M * N;
+  if (x3)
+    PROF_LAUNCH("pgemm_nt_kernel<5>", fl, by, st,
+                hipLaunchKernelGGL((pgemm_nt_kernel<NTW, true>), dim3(grid), dim3(PT), smem, st, (const _Float16*)Ahi,
+                                   (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, C, ldc, N, s_out, nm,
+                                   nslices, dbg));
+  else
+    PROF_LAUNCH("pgemm_nt_kernel<5,f16>", fl, by, st,
+                hipLaunchKernelGGL((pgemm_nt_kernel<NTW, false>), dim3(grid), dim3(PT), smem, st, (const _Float16*)Ahi,
+                                   (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, C, ldc, N, s_out, nm,
+                                   nslices, dbg));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -365,20 +381,27 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
 // shift_T > 0: B row k is taken from row k-1, and from the extra row K (which the producer fills with what the
 // operand looks like at a window start) where k % shift_T == 0.
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
-                    int K, int splitk, float* partial, int Mout, int Nout, hipStream_t st) {
+                    int K, int splitk, float* partial, int Mout, int Nout, bool x3, hipStream_t st) {
   if (lda % 8 != 0 || ldb % 8 != 0) return WGNN_ERR_SHAPE;
   constexpr int MTW = 5;
   const int nMb = cdiv_i(Mout, 32 * MTW), nNb = cdiv_i(Nout, 128);
   const int kchunk = cdiv_i(cdiv_i(K, splitk), 32) * 32;
   const size_t smem = 2 * 4 * 32 * 320;
-  static std::atomic<unsigned long long> done{0};
-  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<MTW>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  static std::atomic<unsigned long long> done{0}, done16{0};
+  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<MTW, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<MTW, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
   const double fl = 2.0 * Mout * (double)Nout * K;
-  const double by = 4.0 * ((double)K * Mout + (double)K * Nout + (double)splitk * Mout * Nout);
-  PROF_LAUNCH("pgemm_tn_kernel<5>", fl, by, st,
-              hipLaunchKernelGGL(pgemm_tn_kernel<MTW>, dim3(splitk, nMb * nNb), dim3(PT), smem, st,
-                                 (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
-                                 (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
+  const double by = (x3 ? 4.0 : 2.0) * ((double)K * Mout + (double)K * Nout) + 4.0 * (double)splitk * Mout * Nout;
+  if (x3)
+    PROF_LAUNCH("pgemm_tn_kernel<5>", fl, by, st,
+                hipLaunchKernelGGL((pgemm_tn_kernel<MTW, true>), dim3(splitk, nMb * nNb), dim3(PT), smem, st,
+                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
+                                   (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
+  else
+    PROF_LAUNCH("pgemm_tn_kernel<5,f16>", fl, by, st,
+                hipLaunchKernelGGL((pgemm_tn_kernel<MTW, false>), dim3(splitk, nMb * nNb), dim3(PT), smem, st,
+                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
+                                   (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
