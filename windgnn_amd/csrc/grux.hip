@@ -79,12 +79,13 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
                                                             _Float16* __restrict__ yp_lo) {
   constexpr int HP = 32 * KS;                      // plane row width (halfs): h, then 1.0 at column H, then 0
   constexpr int HS = 32 * KS + 8;                  // row stride in halfs: 16-B aligned, conflict-free reads
-  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * MB * HS];
-  _Float16* hhi = hbuf;
-  _Float16* hlo = hbuf + MB * HS;
-  for (int i = threadIdx.x; i < 2 * MB * HS; i += NTHREADS) hbuf[i] = (_Float16)0.f;
+  // h state is double-buffered: step t reads buffer t&1 and writes h_t into the other one, so a single
+  // barrier per step suffices (the recurrence is latency-bound: every barrier is on the critical path)
+  __shared__ __attribute__((aligned(16))) _Float16 hbuf[2 * 2 * MB * HS];
+  for (int i = threadIdx.x; i < 2 * 2 * MB * HS; i += NTHREADS) hbuf[i] = (_Float16)0.f;
   __syncthreads();
-  if (threadIdx.x < MB) hhi[threadIdx.x * HS + H] = (_Float16)1.f;   // ones column (W_hh fragments are 0 there)
+  if (threadIdx.x < 2 * MB)   // ones column of both buffers' hi planes (W_hh fragments are 0 there)
+    hbuf[(threadIdx.x / MB) * 2 * MB * HS + (threadIdx.x % MB) * HS + H] = (_Float16)1.f;
 
   if (yp_hi && blockIdx.x == 0 && threadIdx.x < HP) {   // row B*T: what [Hprev | 1] looks like at t = 0
     yp_hi[(size_t)B * T * HP + threadIdx.x] = (_Float16)(threadIdx.x == H ? 1.f : 0.f);
@@ -112,24 +113,28 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     }
   const float bh_r = bhh[jc], bh_z = bhh[H + jc], bh_n = bhh[2 * H + jc];
 
-  // per-row base offsets (clamped so every load is unconditional)
-  size_t rowoff[4];
+  // Addressing: one workgroup-uniform 64-bit base per array (the workgroup's first window) plus 32-bit lane
+  // offsets.  Row indices are clamped so every load is unconditional.
+  const float* GIw = GI + (size_t)b0 * T * ldgi;
+  float* Yw = Y + (size_t)b0 * T * H;
+  float* gatesw = gates ? gates + (size_t)b0 * T * 4 * H : nullptr;
+  int rowt[4];            // (local window row) * T, clamped to the last valid window
   bool rowok[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int b = b0 + 4 * g + r;
-    rowok[r] = jv && b < B;
-    rowoff[r] = (size_t)(b < B ? b : B - 1) * T;
+    const int m = 4 * g + r;
+    rowok[r] = jv && b0 + m < B;
+    rowt[r] = (b0 + m < B ? m : B - 1 - b0) * T;
   }
   float gi[3][4], gin[3][4];
   auto load_gi = [&](int t, float (&dst)[3][4]) {
     const int tc = t < T ? t : T - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float* row = GI + (rowoff[r] + tc) * ldgi + jc;
-      dst[0][r] = row[0];
-      dst[1][r] = row[H];
-      dst[2][r] = row[2 * H];
+      const int o = (rowt[r] + tc) * ldgi + jc;
+      dst[0][r] = GIw[o];
+      dst[1][r] = GIw[o + H];
+      dst[2][r] = GIw[o + 2 * H];
     }
   };
   load_gi(0, gi);
@@ -137,6 +142,10 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
+    const _Float16* hhi = hbuf + (t & 1) * 2 * MB * HS;          // h_{t-1}
+    const _Float16* hlo = hhi + MB * HS;
+    _Float16* nhi = hbuf + ((t + 1) & 1) * 2 * MB * HS;          // h_t goes here
+    _Float16* nlo = nhi + MB * HS;
     load_gi(t + 1, gin);                           // prefetch under this step's MFMAs
     float hnew[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
@@ -164,33 +173,32 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         const float ng = tanh_fast(gi[2][r] + rg * an[r]);
         hnew[r] = (1.f - zg) * ng + zg * hold[r];
         if (rowok[r]) {
-          const size_t bt = rowoff[r] + t;
-          Y[bt * H + j] = hnew[r];
+          const int bt = rowt[r] + t;
+          Yw[bt * H + j] = hnew[r];
           if (gates) {
-            float* gp = gates + bt * 4 * H + j;
-            gp[0] = rg;
-            gp[H] = zg;
-            gp[2 * H] = ng;
-            gp[3 * H] = an[r];
+            const int o = bt * 4 * H + j;
+            gatesw[o] = rg;
+            gatesw[o + H] = zg;
+            gatesw[o + 2 * H] = ng;
+            gatesw[o + 3 * H] = an[r];
           }
         }
         hold[r] = hnew[r];
       }
     }
-    __syncthreads();                               // every wave has read h_{t-1}
     if (active && jv) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) put_split<X3>(hhi, hlo, (4 * g + r) * HS + j, hnew[r]);
+      for (int r = 0; r < 4; ++r) put_split<X3>(nhi, nlo, (4 * g + r) * HS + j, hnew[r]);
     }
-    __syncthreads();
+    __syncthreads();                               // h_t complete; everyone is done reading h_{t-1}
     if (yp_hi) {   // h_t as fp16 planes (the B operand of the dW_hh GEMM): 16-byte chunks straight from LDS
       for (int q = threadIdx.x; q < (X3 ? 2 : 1) * MB * (HP / 8); q += NTHREADS) {
         const int plane = q / (MB * (HP / 8)), rem = q % (MB * (HP / 8));
         const int m = rem / (HP / 8), ch = rem % (HP / 8);
         const int b = b0 + m;
         if (b < B) {
-          const h8 v = *(const h8*)((plane ? hlo : hhi) + m * HS + 8 * ch);
-          *(h8*)((plane ? yp_lo : yp_hi) + ((size_t)b * T + t) * HP + 8 * ch) = v;
+          const h8 v = *(const h8*)((plane ? nlo : nhi) + m * HS + 8 * ch);
+          *(h8*)((plane ? yp_lo : yp_hi) + (size_t)b0 * T * HP + (m * T + t) * HP + 8 * ch) = v;
         }
       }
     }
@@ -217,12 +225,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   constexpr int DS = 32 * KS3 + 8;
   // two [16][DS] fp16 hi/lo tiles: dgh = [dar|daz|dnt*r] (also the MFMA A operand) and dgi = [dar|daz|dnt];
   // both are copied out as 16-byte chunks into the dGH / dGI planes (K padding columns stay zero).
-  __shared__ __attribute__((aligned(16))) _Float16 dbuf[4 * MB * DS];
-  _Float16* dhi = dbuf;
-  _Float16* dlo = dbuf + MB * DS;
-  _Float16* ihi = dbuf + 2 * MB * DS;
-  _Float16* ilo = dbuf + 3 * MB * DS;
-  for (int i = threadIdx.x; i < 4 * MB * DS; i += NTHREADS) dbuf[i] = (_Float16)0.f;
+  // double-buffered (step parity): phase 1 of step t-1 may start writing while slow waves still read step t's tiles
+  __shared__ __attribute__((aligned(16))) _Float16 dbuf2[2 * 4 * MB * DS];
+  for (int i = threadIdx.x; i < 2 * 4 * MB * DS; i += NTHREADS) dbuf2[i] = (_Float16)0.f;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int j = 16 * wave + c;
@@ -244,27 +249,30 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     }
     WT[ks] = split_vals(x);
   }
-  size_t rowoff[4];
+  const float* gatesw = gates + (size_t)b0 * T * 4 * H;     // workgroup-uniform bases + 32-bit lane offsets
+  const float* dYw = dY + (size_t)b0 * T * H;
+  const float* Yw = Y + (size_t)b0 * T * H;
+  int rowt[4];
   bool rowok[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int b = b0 + 4 * g + r;
-    rowok[r] = jv && b < B;
-    rowoff[r] = (size_t)(b < B ? b : B - 1) * T;
+    const int m = 4 * g + r;
+    rowok[r] = jv && b0 + m < B;
+    rowt[r] = (b0 + m < B ? m : B - 1 - b0) * T;
   }
   struct StepIn { float dy[4], r[4], z[4], n[4], ghn[4], hp[4]; };
   auto load_step = [&](int t, StepIn& s) {
     const int tc = t > 0 ? t : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t bt = rowoff[r] + tc;
-      const float* gp = gates + bt * 4 * H + jc;
-      s.dy[r] = dY[bt * H + jc];
-      s.r[r] = gp[0];
-      s.z[r] = gp[H];
-      s.n[r] = gp[2 * H];
-      s.ghn[r] = gp[3 * H];
-      const float hp = Y[(bt - (tc > 0 ? 1 : 0)) * H + jc];
+      const int bt = rowt[r] + tc;
+      const int o = bt * 4 * H + jc;
+      s.dy[r] = dYw[bt * H + jc];
+      s.r[r] = gatesw[o];
+      s.z[r] = gatesw[o + H];
+      s.n[r] = gatesw[o + 2 * H];
+      s.ghn[r] = gatesw[o + 3 * H];
+      const float hp = Yw[(bt - (tc > 0 ? 1 : 0)) * H + jc];
       s.hp[r] = tc > 0 ? hp : 0.f;
     }
   };
@@ -274,6 +282,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
+    _Float16* dbuf = dbuf2 + (t & 1) * 4 * MB * DS;
+    _Float16* dhi = dbuf;
+    _Float16* dlo = dbuf + MB * DS;
+    _Float16* ihi = dbuf + 2 * MB * DS;
+    _Float16* ilo = dbuf + 3 * MB * DS;
     load_step(t - 1, nxt);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (active) {
@@ -312,9 +325,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
         const int m = rem / cpr, ch = rem % cpr;
         const int b = b0 + m;
         if (b < B && (X3 || (buf & 1) == 0)) {        // f16 mode: hi planes only
-          const h8 v = *(const h8*)(dbuf + (size_t)buf * MB * DS + m * DS + 8 * ch);
+          const h8 v = *(const h8*)(dbuf + buf * MB * DS + m * DS + 8 * ch);
           _Float16* dst = buf == 0 ? dGH_hi : (buf == 1 ? dGH_lo : (buf == 2 ? dGI_hi : dGI_lo));
-          *(h8*)(dst + ((size_t)b * T + t) * ldd + 8 * ch) = v;
+          *(h8*)(dst + (size_t)b0 * T * ldd + (m * T + t) * ldd + 8 * ch) = v;
         }
       }
     }
@@ -329,7 +342,6 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
       }
     }
     dhn = acc;
-    __syncthreads();
     cur = nxt;
   }
 }
