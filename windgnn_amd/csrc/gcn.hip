@@ -310,29 +310,29 @@ __global__ void __launch_bounds__(256) gcn_bwd_kernel(int ntiles, int S, int F, 
 }
 
 // sum partial rows (fixed order => bitwise reproducible) and scatter into the [F,F]/[F] gradients.
-// One block per 32 columns; 8 row-groups per block keep 32 independent loads in flight per column.
-__global__ void __launch_bounds__(256) gcn_partial_reduce_kernel(const float* __restrict__ partial, int nblk, int F,
-                                                                 float* dW1, float* db1, float* dW2, float* db2) {
-  __shared__ float sm[8][33];
+// One block per 32 columns; 32 row-groups per block (1024 threads) keep many independent loads in flight.
+__global__ void __launch_bounds__(1024) gcn_partial_reduce_kernel(const float* __restrict__ partial, int nblk, int F,
+                                                                  float* dW1, float* db1, float* dW2, float* db2) {
+  __shared__ float sm[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + tx;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < PART) {
     int b = ty;
-    for (; b + 24 < nblk; b += 32) {
+    for (; b + 96 < nblk; b += 128) {
       s0 += partial[(size_t)b * PART + i];
-      s1 += partial[(size_t)(b + 8) * PART + i];
-      s2 += partial[(size_t)(b + 16) * PART + i];
-      s3 += partial[(size_t)(b + 24) * PART + i];
+      s1 += partial[(size_t)(b + 32) * PART + i];
+      s2 += partial[(size_t)(b + 64) * PART + i];
+      s3 += partial[(size_t)(b + 96) * PART + i];
     }
-    for (; b < nblk; b += 8) s0 += partial[(size_t)b * PART + i];
+    for (; b < nblk; b += 32) s0 += partial[(size_t)b * PART + i];
   }
   sm[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ty != 0 || i >= PART) return;
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) s += sm[k][tx];
+  for (int k = 0; k < 32; ++k) s += sm[k][tx];
   if (i < FP * FP) {
     int r = i / FP, c = i % FP;
     if (dW1 && r < F && c < F) dW1[r * F + c] = s;
@@ -363,7 +363,7 @@ size_t smem_bytes(int S) {
 int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
                               hipStream_t st) {
   PROF_LAUNCH("gcn_partial_reduce_kernel", (double)nblk * PART, 4.0 * nblk * PART, st,
-              hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(256), 0, st, partial, nblk,
+              hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(1024), 0, st, partial, nblk,
                                  13, dW1, db1, dW2, db2));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
@@ -402,7 +402,7 @@ int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const flo
               hipLaunchKernelGGL(gcn_bwd_kernel<2>, dim3(grid), dim3(256), smem_bytes(S), st, ntiles, S, 13, A, X, W1,
                                  b1, W2, g, dg, (float*)nullptr, partial, ldg));
   WGNN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(256), 0, st, partial, grid, 13, dW1,
+  hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(1024), 0, st, partial, grid, 13, dW1,
                      db1, dW2, db2);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
@@ -414,7 +414,7 @@ int launch_gcn1_bwd(int ntiles, int S, const float* A, const float* X, const flo
   hipLaunchKernelGGL(gcn_bwd_kernel<1>, dim3(grid), dim3(256), smem_bytes(S), st, ntiles, S, 13, A, X, W,
                      (const float*)nullptr, (const float*)nullptr, out, dout, dX, partial, S * 13);
   WGNN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(256), 0, st, partial, grid, 13, dW,
+  hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(1024), 0, st, partial, grid, 13, dW,
                      db, (float*)nullptr, (float*)nullptr);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;

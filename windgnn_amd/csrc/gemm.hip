@@ -122,16 +122,20 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * N) return;
   const size_t MN = (size_t)M * N;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
   int z = 0;
-  for (; z + 4 <= splitk; z += 4) {        // 4 independent loads in flight; fixed order => deterministic
+  for (; z + 8 <= splitk; z += 8) {        // 8 independent loads in flight; fixed order => deterministic
     s0 += partial[(size_t)z * MN + i];
     s1 += partial[(size_t)(z + 1) * MN + i];
     s2 += partial[(size_t)(z + 2) * MN + i];
     s3 += partial[(size_t)(z + 3) * MN + i];
+    s4 += partial[(size_t)(z + 4) * MN + i];
+    s5 += partial[(size_t)(z + 5) * MN + i];
+    s6 += partial[(size_t)(z + 6) * MN + i];
+    s7 += partial[(size_t)(z + 7) * MN + i];
   }
   for (; z < splitk; ++z) s0 += partial[(size_t)z * MN + i];
-  float s = (s0 + s1) + (s2 + s3);
+  float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   if (scales) s *= scales[1];
   int m = (int)(i / N), n = (int)(i % N);
   if (n < ncols_main) C[(size_t)m * ldc + n] = s;
