@@ -111,14 +111,17 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
              const float* Y, const float* dY, const void* stash, const wgnn_grads* g,
              void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same backward in two parts, for data-parallel callers that want to overlap the gradient
- * all-reduce with the rest of the backward (no reference counterpart: it has no collectives):
- *   part = 1: BPTT + dW_ih, db_ih, dW_hh, db_hh (99.8 % of the gradient bytes) are final on return;
- *   part = 2: dg and the four conv gradients (needs part 1 to have run on the same workspace);
- *   part = 3: both (== wgnn_bwd). */
+/* The same backward in parts, for callers that overlap them (no reference counterpart: it has no
+ * streams or collectives).  `part` is a bit mask, wgnn_bwd == 7:
+ *   1  BPTT recurrence (reads dY; writes the dGI / dGH buffers in the workspace);
+ *   4  weight-gradient GEMMs: dW_ih, db_ih, dW_hh, db_hh (99.8 % of the gradient bytes) final on return;
+ *   2  dg GEMM + GCN backward: the four conv gradients final on return.
+ * Parts 4 and 2 only read what part 1 wrote and use disjoint scratch, so after part 1 they may run
+ * concurrently on two streams (ordered after part 1 by events), and a data-parallel caller can start
+ * all-reducing the GRU gradients as soon as part 4 is done. */
 int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p,
                   const float* Y, const float* dY, const void* stash, const wgnn_grads* g,
-                  void* workspace, size_t workspace_bytes, void* stream, int part /* 1, 2 or 3 */);
+                  void* workspace, size_t workspace_bytes, void* stream, int part /* bit mask 1..7 */);
 
 /* One GraphConvLayer: out[n,S,F] = relu(A X[n] W + b) for n = 0..ntiles-1 (ntiles = prod of the
  * leading dims of attr_matrix).  Backward: dW, db (overwritten) and, if dX != NULL, dX. */

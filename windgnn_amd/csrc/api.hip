@@ -170,14 +170,14 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
 int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
              const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
              void* stream) {
-  return wgnn_bwd_part(d, A, X, p, Y, dY, stash, g, workspace, workspace_bytes, stream, 3);
+  return wgnn_bwd_part(d, A, X, p, Y, dY, stash, g, workspace, workspace_bytes, stream, 7);
 }
 
 int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
                   const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
                   void* stream, int which) {
-  if (which < 1 || which > 3) return WGNN_ERR_SHAPE;
-  const bool do_gru = which & 1, do_gcn = which & 2;
+  if (which < 1 || which > 7) return WGNN_ERR_SHAPE;
+  const bool do_rec = which & 1, do_gcn = which & 2, do_wg = which & 4;
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
   if (!A || !X || !p || !Y || !dY || !stash || !g || !workspace) return WGNN_ERR_NULL;
@@ -207,11 +207,13 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     const _Float16* gh = (const _Float16*)gact;
     const _Float16* yph = (const _Float16*)(sf + L.st_yp);
     const size_t PG = L.BT * L.Gp;
-    if (do_gru) {
+    if (do_rec) {
     rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
     if (rc != WGNN_OK) return rc;
     rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
     if (rc != WGNN_OK) return rc;
+    }
+    if (do_wg) {
     // dW_hh | db_hh = dGH^T [Hprev | 1]   (Hprev row (b,t) = Y-plane row (b,t-1), zero at t = 0)
     rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT, L.sk_hh, part,
                          (int)L.G3, (int)L.H + 1, full, st);
@@ -239,9 +241,11 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
                                      g->conv2_weight, g->conv2_bias, st);
   }
 
-  if (do_gru) {
+  if (do_rec) {
     rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;
+  }
+  if (do_wg) {
     // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
     GemmArgs a = {};
     a.A = dGH; a.lda = (int)L.Gp; a.a_kcontig = 0;

@@ -75,15 +75,15 @@ def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32
     return Y, stash, d
 
 
-def gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, grads: Sequence[torch.Tensor], part: int = 3):
-    """part: 1 = recurrence + GRU weight gradients, 2 = dg + conv gradients, 3 = all (wgnn_bwd_part)."""
+def gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, grads: Sequence[torch.Tensor], part: int = 7, stream=None):
+    """part bit mask (wgnn_bwd_part): 1 = BPTT recurrence, 4 = GRU weight-gradient GEMMs, 2 = dg + GCN backward."""
     lib = _lib.load()
     ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
     ws = _Workspace.get(X.device, ws_bytes)
     ps = _params_struct(_lib.Params, params)
     gs = _params_struct(_lib.Grads, grads)
     rc = lib.wgnn_bwd_part(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(Y), _ptr(dY), _ptr(stash), C.byref(gs),
-                           _ptr(ws), ws_bytes, _stream(), part)
+                           _ptr(ws), ws_bytes, _stream() if stream is None else C.c_void_p(stream.cuda_stream), part)
     _lib.check(rc, "wgnn_bwd_part(%d)" % part)
 
 

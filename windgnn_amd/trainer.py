@@ -53,7 +53,7 @@ class TrainStep:
             # step) still computes; the 364 conv gradients follow in a second, tiny all-reduce.
             Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True)
             loss, dY = mse_loss_grad(Y, L, grad_scale=1.0 / self.world)
-            gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views, part=1)
+            gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views, part=1 | 4)
             n_conv = sum(g.numel() for g in self.g_views[:4])
             work = torch.distributed.all_reduce(self.flat_g[n_conv:], group=self.group, async_op=True)
             gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views, part=2)
