@@ -208,24 +208,26 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     const _Float16* yph = (const _Float16*)(sf + L.st_yp);
     const size_t PG = L.BT * L.Gp;
     if (do_rec) {
-    rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
-    if (rc != WGNN_OK) return rc;
-    rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
-    if (rc != WGNN_OK) return rc;
+      rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
+      if (rc != WGNN_OK) return rc;
+      rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
+      if (rc != WGNN_OK) return rc;
     }
     if (do_wg) {
-    // dW_hh | db_hh = dGH^T [Hprev | 1]   (Hprev row (b,t) = Y-plane row (b,t-1), zero at t = 0)
-    rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT, L.sk_hh, part,
-                         (int)L.G3, (int)L.H + 1, full, st);
-    if (rc != WGNN_OK) return rc;
-    rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales, st);
-    if (rc != WGNN_OK) return rc;
-    // dW_ih | db_ih = dGI^T [g | 1]
-    rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part,
-                         (int)L.G3, (int)L.I + 1, full, st);
-    if (rc != WGNN_OK) return rc;
-    rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales, st);
-    if (rc != WGNN_OK) return rc;
+      // dW_hh | db_hh = dGH^T [Hprev | 1]   (Hprev row (b,t) = Y-plane row (b,t-1); row B*T stands in at t = 0)
+      rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
+                           L.sk_hh, part, (int)L.G3, (int)L.H + 1, full, st);
+      if (rc != WGNN_OK) return rc;
+      rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
+                                st);
+      if (rc != WGNN_OK) return rc;
+      // dW_ih | db_ih = dGI^T [g | 1]
+      rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part,
+                           (int)L.G3, (int)L.I + 1, full, st);
+      if (rc != WGNN_OK) return rc;
+      rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales,
+                                st);
+      if (rc != WGNN_OK) return rc;
     }   // the four GRU gradients are final here: a data-parallel caller can start reducing them now
     if (!do_gcn) return WGNN_OK;
     // dg = dGI W_ih   (B operand = split(W_ih^T) [np_i][Gp]); dg stays in scaled units

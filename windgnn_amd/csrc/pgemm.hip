@@ -15,8 +15,6 @@
 // TN operands are K-strided in memory, so tiles are staged row-major [k][cols] exactly as they lie
 // in HBM and the MFMA fragments are formed by ds_read_b64_tr_b16 (hardware transpose read); the row
 // stride of 320 B (== 64 mod 256) makes the 4 rows x 64 B touched by a half-wave conflict-free.
-#include <stdlib.h>
-
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -41,8 +39,7 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
                                                          const _Float16* __restrict__ Alo, int lda, int M, int Kp,
                                                          const _Float16* __restrict__ Bpl, int Np,
                                                          float* __restrict__ C, int ldc, int N,
-                                                         const float* __restrict__ s_out_p, int nm, int nslices,
-                                                         int dbg) {
+                                                         const float* __restrict__ s_out_p, int nm, int nslices) {
   constexpr int BM = 128, BN = 32 * NT_W, STAGE = (2 * BM + 2 * BN) * 64;
   constexpr int RING = 2;   // 2 x 36 KB stages => two workgroups per CU (measured: beats a 4-deep ring at 1 WG/CU, 111 vs 174 us)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,10 +146,9 @@ __global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restr
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // all waves: stage kt visible, stage kt-1 no longer being read
-    if (kt + RING - 1 < nk && !(dbg & 1)) dma_stage(smem + ((kt + RING - 1) % RING) * STAGE, kt + RING - 1);
-    if (!(dbg & 2)) compute(smem + (kt % RING) * STAGE);
+    if (kt + RING - 1 < nk) dma_stage(smem + ((kt + RING - 1) % RING) * STAGE, kt + RING - 1);
+    compute(smem + (kt % RING) * STAGE);
   }
-  if (dbg & 16) return;
 
 #pragma unroll
   for (int j = 0; j < NT_W; ++j) {
@@ -354,7 +350,6 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
                     int ldc, int N, const float* s_out, bool x3, hipStream_t st) {
   if (Kp % 32 != 0 || lda % 8 != 0 || Np % 160 != 0) return WGNN_ERR_SHAPE;
   constexpr int NTW = 5;
-  static const int dbg = getenv("WGNN_DBG_NT") ? atoi(getenv("WGNN_DBG_NT")) : 0;   // timing ablations only
   const int nm = cdiv_i(M, 128), nslices = Np / 160;
   const int grid = cdiv_i(nm, 8) * 8 * nslices;
   const size_t smem = 2 * (size_t)(2 * 128 + 2 * 32 * NTW) * 64;
@@ -367,12 +362,12 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
     PROF_LAUNCH("pgemm_nt_kernel<5>", fl, by, st,
                 hipLaunchKernelGGL((pgemm_nt_kernel<NTW, true>), dim3(grid), dim3(PT), smem, st, (const _Float16*)Ahi,
                                    (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, C, ldc, N, s_out, nm,
-                                   nslices, dbg));
+                                   nslices));
   else
     PROF_LAUNCH("pgemm_nt_kernel<5,f16>", fl, by, st,
                 hipLaunchKernelGGL((pgemm_nt_kernel<NTW, false>), dim3(grid), dim3(PT), smem, st, (const _Float16*)Ahi,
                                    (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, C, ldc, N, s_out, nm,
-                                   nslices, dbg));
+                                   nslices));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
