@@ -12,9 +12,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libwindgnn_hip.so")
 SOURCES = ["api.hip", "gcn.hip", "gemm.hip", "gru.hip", "train_ops.hip", "prof.hip", "gcnx.hip", "grux.hip", "pgemm.hip", "data_ops.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "windgnn.h")]
-# (Tried: -mllvm -amdgpu-mfma-vgpr-form removes the v_accvgpr_read per accumulator value, but then the inline-asm
-# fp16 split reads MFMA results with no hazard padding -> wrong data; worth only ~4 % on the GCN kernels.)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("WGNN_HIPCC_FLAGS", "").split()   # experiments only; the default build takes none
 
 
 def _stale() -> bool:

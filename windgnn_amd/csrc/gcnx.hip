@@ -47,21 +47,24 @@ __device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
 // hi = fp16(x) (v_cvt_pk_f16_f32, 2 values per instruction), lo = fp16(x - hi) with the difference
 // formed by v_fma_mix_f32 reading hi straight out of the packed register: 2 VALU per value instead
 // of the 3 hipcc emits for the C expression (these kernels are VALU-issue-bound on exactly this).
+// The hi conversion stays a compiler-visible instruction: x is usually an MFMA result, and the
+// XDL-write -> VALU-read wait states are only inserted for instructions the hazard recognizer can
+// see (an asm block reading a VGPR-form MFMA result directly gets none and reads stale registers).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt2(float x0, float x1) {
+  const f32x2 xv = {x0, x1};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(xv, h2));
+}
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
   float t0, t1;
-  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
-      "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_cvt_pk_f16_f32 %1, %2, %3\n\t"
+  hi = cvt2(x0, x1);
+  asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_cvt_pk_f16_f32 %0, %1, %2\n\t"
       "s_nop 1"   // VALU write -> MFMA operand read needs 2 wait states; hipcc pads nothing inside/after asm
-      : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1)
-      : "v"(x0), "v"(x1));
-}
-__device__ __forceinline__ void cvt2(float x0, float x1, unsigned& hi) {
-  asm("v_cvt_pk_f16_f32 %0, %1, %2\n\t"
-      "s_nop 1"
-      : "=v"(hi)
-      : "v"(x0), "v"(x1));
+      : "=&v"(lo), "=&v"(t0), "=&v"(t1)
+      : "v"(hi), "v"(x0), "v"(x1));
 }
 template <bool X3>
 __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
@@ -71,7 +74,7 @@ __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
   for (int j = 0; j < 4; ++j) {
     unsigned h, l = 0u;
     if (X3) split2(x[2 * j], x[2 * j + 1], h, l);
-    else cvt2(x[2 * j], x[2 * j + 1], h);
+    else h = cvt2(x[2 * j], x[2 * j + 1]);
     hi[j] = h;
     lo[j] = l;
   }
@@ -137,8 +140,6 @@ struct PairMap {
     }
   }
 };
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 template <int NP>
 __device__ __forceinline__ void gload_pairs(f32x2 (&r)[NP], const float* __restrict__ src, int lane, int I) {
@@ -174,8 +175,10 @@ __device__ __forceinline__ Frag xfrag_nat(const float* xb, int i, int c, int g) 
   return split_vals<X3>(x);
 }
 
+constexpr int FWD_WAVES = 8;   // waves per forward block (A fragments are shared through LDS)
+
 template <int NT, bool X3>
-__global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
+__global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const float* __restrict__ b2, _Float16* __restrict__ ghi,
@@ -184,15 +187,32 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
   constexpr int SP = 16 * NT;
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
   static_assert(128 * NP >= (SP * F13 + 1 + 31) / 32 * 32, "pair map must cover the padded row");
-  __shared__ __attribute__((aligned(16))) float sbuf[4 * 2 * SP * XS];
+  constexpr int NF = NT * KS;
+  __shared__ __attribute__((aligned(16))) h8 sCA[2 * NF * 64];   // A fragments [frag][hi|lo][lane]
+  __shared__ __attribute__((aligned(16))) float sbuf[FWD_WAVES * 2 * SP * XS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int I = S * F13;
   float* xb = sbuf + wave * 2 * SP * XS;
   float* ob = xb + SP * XS;                           // output staging [s][XS] fp32 (one b128 store per n-tile)
   for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;   // pads (f >= 13, s >= S) stay zero forever
-
-  Frag CA[NT][KS];
-  build_A_frags<NT, KS, false, X3>(CA, A, S, c, g);
+  if (wave == 0) {
+    Frag T[NT][KS];
+    build_A_frags<NT, KS, false, X3>(T, A, S, c, g);
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sCA[((mi * KS + ks) * 2 + 0) * 64 + lane] = T[mi][ks].hi;
+        sCA[((mi * KS + ks) * 2 + 1) * 64 + lane] = T[mi][ks].lo;
+      }
+  }
+  __syncthreads();
+  auto ldA = [&](int mi, int ks) {
+    Frag f;
+    f.hi = sCA[((mi * KS + ks) * 2 + 0) * 64 + lane];
+    f.lo = sCA[((mi * KS + ks) * 2 + 1) * 64 + lane];
+    return f;
+  };
   Frag FW1, FW2;
   float bb1[4], bb2[4];
   {
@@ -235,6 +255,7 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
     stage_x();
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
+    asm volatile("" ::: "memory");                    // keep the A-fragment reads in LDS (no hoisting into VGPRs)
     wave_lds_fence();                                 // this tile's X is staged
     const bool more = tile + nwaves < ntiles;
     if (more) gload_pairs<NP>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch the next tile
@@ -250,7 +271,7 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
     for (int n = 0; n < NT; ++n) {
       f32x4 acc = zero4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], CA[n][ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) Ht[n][r] = fmaxf(acc[r] + bb1[r], 0.f);
     }
@@ -262,7 +283,7 @@ __global__ void __launch_bounds__(256) gcnx_fwd_kernel(int ntiles, int S, const 
     for (int n = 0; n < NT; ++n) {
       f32x4 acc = zero4;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], CA[n][ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bb2[r], 0.f);
@@ -535,15 +556,17 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const fl
   _Float16* glo = ghi + (size_t)ntiles * ldg;
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
   const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
-  const dim3 grid(grid_x(ntiles));
+  int gx = cdiv_i(ntiles, FWD_WAVES);
+  gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+  const dim3 grid(gx);
 #define FWD_CASE(NT)                                                                                              \
   if (x3)                                                                                                         \
     PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                           \
-                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, true>), grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, b2, \
+                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, true>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, b2, \
                                    ghi, glo, ldg));                                                               \
   else                                                                                                            \
     PROF_LAUNCH("gcnx_fwd_kernel<" #NT ",f16>", fl, by * 0.75, st,                                                \
-                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, false>), grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, \
+                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, false>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, \
                                    b2, ghi, glo, ldg))
   switch ((S + 15) / 16) {
     case 1: FWD_CASE(1); break;
