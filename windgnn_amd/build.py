@@ -12,7 +12,11 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libwindgnn_hip.so")
 SOURCES = ["api.hip", "gcn.hip", "gemm.hip", "gru.hip", "train_ops.hip", "prof.hip", "gcnx.hip", "grux.hip", "pgemm.hip", "data_ops.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "windgnn.h")]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs, so no v_accvgpr_read per value in the VALU-bound
+# GCN/GRU kernels (gcnx_bwd -8 %).  Safe only because every first read of an MFMA result is a compiler-visible
+# instruction (see split2 in gcnx.hip).
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 FLAGS += os.environ.get("WGNN_HIPCC_FLAGS", "").split()   # experiments only; the default build takes none
 
 

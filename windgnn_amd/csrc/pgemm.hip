@@ -15,6 +15,8 @@
 // TN operands are K-strided in memory, so tiles are staged row-major [k][cols] exactly as they lie
 // in HBM and the MFMA fragments are formed by ds_read_b64_tr_b16 (hardware transpose read); the row
 // stride of 320 B (== 64 mod 256) makes the 4 rows x 64 B touched by a half-wave conflict-free.
+#include <string>
+
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -22,6 +24,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef PG_ABL
+#define PG_ABL 0
+#endif
 namespace {
 
 constexpr int PT = 256;   // 4 waves
@@ -33,132 +38,150 @@ __device__ __forceinline__ f32x16 mfma_h(h8 a, h8 b, f32x16 c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// NT.  BM = 128 (wave w owns rows 32w..32w+31), BN = 32*NT_W columns (one N slice per block).
-template <int NT_W, bool X3>
-__global__ void __launch_bounds__(PT, 2) pgemm_nt_kernel(const _Float16* __restrict__ Ahi,
-                                                         const _Float16* __restrict__ Alo, int lda, int M, int Kp,
-                                                         const _Float16* __restrict__ Bpl, int Np,
-                                                         float* __restrict__ C, int ldc, int N,
-                                                         const float* __restrict__ s_out_p, int nm, int nslices) {
-  constexpr int BM = 128, BN = 32 * NT_W, STAGE = (2 * BM + 2 * BN) * 64;
-  constexpr int RING = 2;   // 2 x 36 KB stages => two workgroups per CU (measured: beats a 4-deep ring at 1 WG/CU, 111 vs 174 us)
+// NT.  One 12-wave workgroup per CU owns a 192 x 32T tile: waves 6 (M) x 2 (N), wave tile 32 x 16T
+// built from v_mfma_f32_16x16x32_f16 (K step = one 64-byte LDS row).  Under MFMA load the chip
+// clocks down (~1.45 GHz here) and with it the CU's load path, which is what bounds this kernel:
+// the tile is as tall and as wide as LDS allows so that the fewest bytes cross L2 -> LDS per MFMA
+// (A is staged once per M tile when N <= 320, B once per 192 rows).
+constexpr int NT_BM = 192, NT_WAVES = 12;
+
+// 16-byte chunk c of 64-byte row `row` sits at chunk c ^ f(row): conflict-free for the 16-lane
+// groups of ds_read_b128 when lane l reads chunk l>>4 of row l&15.
+__device__ __forceinline__ int swz16(int row) { return (4 - (row >> 2)) & 3; }
+__device__ __forceinline__ int sw16_off(int row, int c) { return row * 64 + ((c ^ swz16(row)) << 4); }
+
+__device__ __forceinline__ f32x4 mfma_q(h8 a, h8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int T, bool X3>
+__global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16* __restrict__ Ahi,
+                                                                const _Float16* __restrict__ Alo, int lda, int M,
+                                                                int Kp, const _Float16* __restrict__ Bpl, int Np,
+                                                                float* __restrict__ C, int ldc, int N,
+                                                                const float* __restrict__ s_out_p, int nm, int nsl) {
+  constexpr int BM = NT_BM, BNW = 16 * T, BN = 2 * BNW;
+  constexpr int A_PL = BM * 64, B_PL = BN * 64, STAGE = 2 * A_PL + 2 * B_PL;
+  constexpr int PL = X3 ? 2 : 1;                                   // planes moved: hi (+ lo)
+  constexpr int AP = BM / 16, BP = BN / 16;                        // 1 KB pieces per plane
+  constexpr int NPIECE = PL * (AP + BP), NIT = (NPIECE + NT_WAVES - 1) / NT_WAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases go to M0
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: LDS-DMA bases go to M0
+  const int wm = wave % 6, wn = wave / 6;
   // blocks {b, b+8, ...} (same XCD, dispatched together) are the N slices of one M tile: the A tile is
   // fetched from HBM once and re-read from that XCD's L2 by the sibling slices.
-  const int grp = blockIdx.x / (8 * nslices), within = blockIdx.x % (8 * nslices);
-  const int slice = within / 8, mt = grp * 8 + within % 8;
+  const int grp = blockIdx.x / (8 * nsl), within = blockIdx.x % (8 * nsl);
+  const int sl = within / 8, mt = grp * 8 + within % 8;
   if (mt >= nm) return;
-  const int m0 = mt * BM, n0 = slice * BN;
+  const int m0 = mt * BM, n0 = sl * BN;
   const float s_out = s_out_p ? s_out_p[1] : 1.f;
 
-  f32x16 acc[NT_W];
+  f32x4 acc[2][T];
 #pragma unroll
-  for (int j = 0; j < NT_W; ++j)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < T; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- LDS-DMA staging (global_load_lds_dwordx4): no VGPRs, no ds_write, and no compiler-inserted
-  // vmcnt waits in the way (with register staging hipcc waited for the NEW loads before every
-  // ds_write of the OLD ones, so loads never overlapped the MFMAs).  One wave-instruction moves a
-  // 1 KB "piece" = 16 tile rows x 64 B; the LDS image is lane-linear, so the XOR swizzle the fragment
-  // reads expect is applied to the SOURCE chunk index: LDS (row, pos) <- global chunk pos ^ ((row>>2)&3).
-  constexpr int PL = X3 ? 2 : 1;                                        // planes moved: hi (+ lo)
-  constexpr int APIECES = PL * BM / 16, BPIECES = PL * BN / 16;        // per stage
-  constexpr int NPA = APIECES / 4, NPB = (BPIECES + 3) / 4;            // per wave
+  // ---- LDS-DMA staging (global_load_lds_dwordx4): no VGPRs, no ds_write.  One wave-instruction moves
+  // a 1 KB "piece" = 16 tile rows x 64 B; the LDS image is lane-linear, so the swizzle the fragment
+  // reads expect is applied to the SOURCE chunk index: LDS (row, pos) <- global chunk pos ^ f(row).
   const int prow = lane >> 2, ppos = lane & 3;
-  const _Float16* a_src[NPA];
-  int a_dst[NPA];
+  const _Float16* src[NIT];
+  int dst[NIT], kadv[NIT];
+  bool on[NIT];
 #pragma unroll
-  for (int it = 0; it < NPA; ++it) {
-    const int p = wave + 4 * it;
-    const int plane = p / (BM / 16), row = 16 * (p % (BM / 16)) + prow;
-    const int gr = min(m0 + row, M - 1);                 // rows past M are computed but never stored
-    a_src[it] = (plane ? Alo : Ahi) + (size_t)gr * lda + 8 * (ppos ^ ((row >> 2) & 3));
-    a_dst[it] = plane * BM * 64 + 16 * (p % (BM / 16)) * 64;            // wave-uniform piece base
-  }
-  const _Float16* b_src[NPB];
-  int b_dst[NPB];
-  bool b_on[NPB];
-#pragma unroll
-  for (int it = 0; it < NPB; ++it) {
-    const int p = wave + 4 * it;
-    b_on[it] = p < BPIECES;                              // wave-uniform
-    const int pp = b_on[it] ? p : 0;
-    const int plane = pp / (BN / 16), row = 16 * (pp % (BN / 16)) + prow;
-    b_src[it] = Bpl + (size_t)plane * Np * Kp + (size_t)(n0 + row) * 32 + 8 * (ppos ^ ((row >> 2) & 3));
-    b_dst[it] = 2 * BM * 64 + plane * BN * 64 + 16 * (pp % (BN / 16)) * 64;
+  for (int it = 0; it < NIT; ++it) {
+    const int p = wave + NT_WAVES * it;
+    on[it] = p < NPIECE;                                            // wave-uniform
+    const int pp = on[it] ? p : 0;
+    const int chunk = 8 * (ppos ^ swz16(prow));
+    if (pp < PL * AP) {
+      const int plane = pp / AP, blk = pp % AP;
+      const int gr = min(m0 + 16 * blk + prow, M - 1);            // rows past M are computed but never stored
+      src[it] = (plane ? Alo : Ahi) + (size_t)gr * lda + chunk;
+      dst[it] = plane * A_PL + blk * 1024;
+      kadv[it] = 32;
+    } else {
+      const int q = pp - PL * AP;
+      const int plane = q / BP, blk = q % BP;
+      src[it] = Bpl + (size_t)plane * Np * Kp + (size_t)(n0 + 16 * blk + prow) * 32 + chunk;
+      dst[it] = 2 * A_PL + plane * B_PL + blk * 1024;
+      kadv[it] = Np * 32;
+    }
   }
   const int nk = Kp / 32;
-  const size_t bkt = (size_t)Np * 32;
-  const int li = lane & 31, lh = lane >> 5;
+  const int r16 = lane & 15, c4 = lane >> 4;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef __attribute__((address_space(1))) const void glb_void;
 
   auto dma_stage = [&](char* st, int kt) {
 #pragma unroll
-    for (int it = 0; it < NPA; ++it)
-      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[it] + 32 * kt), (lds_void*)(st + a_dst[it]), 16, 0, 0);
-#pragma unroll
-    for (int it = 0; it < NPB; ++it)
-      if (b_on[it])
-        __builtin_amdgcn_global_load_lds((glb_void*)(b_src[it] + bkt * kt), (lds_void*)(st + b_dst[it]), 16, 0, 0);
+    for (int it = 0; it < NIT; ++it)
+      if (on[it])
+        __builtin_amdgcn_global_load_lds((glb_void*)(src[it] + (size_t)kadv[it] * kt), (lds_void*)(st + dst[it]), 16, 0,
+                                         0);
   };
+  const int a_off0 = sw16_off(32 * wm + r16, c4), a_off1 = a_off0 + 16 * 64;
+  const int b_off = sw16_off(BNW * wn + r16, c4);
   auto compute = [&](const char* cur) {
     const char* Ah = cur;
-    const char* Al = cur + BM * 64;
-    const char* Bh = cur + 2 * BM * 64;
-    const char* Bl = Bh + BN * 64;
+    const char* Al = cur + A_PL;
+    const char* Bh = cur + 2 * A_PL + b_off;
+    const char* Bl = Bh + B_PL;
+    h8 ah[2], al[2];
+    ah[0] = *(const h8*)(Ah + a_off0);
+    ah[1] = *(const h8*)(Ah + a_off1);
+    al[0] = ah[0];
+    al[1] = ah[1];
+    if (X3) {
+      al[0] = *(const h8*)(Al + a_off0);
+      al[1] = *(const h8*)(Al + a_off1);
+    }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int c = 2 * ks + lh;
-      const int aoff = sw_off(32 * wave + li, c);
-      const h8 ah = *(const h8*)(Ah + aoff);
-      h8 al = ah;
-      if (X3) al = *(const h8*)(Al + aoff);
+    for (int j = 0; j < T; ++j) {
+      const h8 bh = *(const h8*)(Bh + j * 1024);
+      if (X3) {
+        const h8 bl = *(const h8*)(Bl + j * 1024);
 #pragma unroll
-      for (int j = 0; j < NT_W; ++j) {
-        const int boff = sw_off(32 * j + li, c);
-        const h8 bh = *(const h8*)(Bh + boff);
-        if (X3) {
-          const h8 bl = *(const h8*)(Bl + boff);
-          acc[j] = mfma_h(al, bh, acc[j]);
-          acc[j] = mfma_h(ah, bl, acc[j]);
+        for (int i = 0; i < 2; ++i) {
+          acc[i][j] = mfma_q(al[i], bh, acc[i][j]);
+          acc[i][j] = mfma_q(ah[i], bl, acc[i][j]);
         }
-        acc[j] = mfma_h(ah, bh, acc[j]);
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = mfma_q(ah[i], bh, acc[i][j]);
     }
   };
 
-  // RING-deep LDS ring: stage kt+RING-1 is issued while stage kt is multiplied, so RING-1 stages of
-  // DMA are in flight per workgroup (the kernel is bound by memory latency x bytes in flight, not by
-  // issue).  vmcnt is counted: (RING-2) stages * (NPA+NPB) DMA instructions may stay outstanding.
-  constexpr int PER = NPA + NPB;
-  static_assert(RING == 2 || BPIECES % 4 == 0, "counted vmcnt needs the same DMA count in every wave");
-#pragma unroll
-  for (int s0 = 0; s0 < RING - 1; ++s0)
-    if (s0 < nk) dma_stage(smem + s0 * STAGE, s0);
+  // Two-stage ring: stage kt+1 is in flight while stage kt is multiplied.
+  dma_stage(smem, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once at most the DMA of the (up to RING-2) younger stages is outstanding
-    const int younger = min(RING - 2, nk - 1 - kt);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // all waves: stage kt visible, stage kt-1 no longer being read
-    if (kt + RING - 1 < nk) dma_stage(smem + ((kt + RING - 1) % RING) * STAGE, kt + RING - 1);
-    compute(smem + (kt % RING) * STAGE);
+#if PG_ABL != 1
+    if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kt + 1);
+#endif
+#if PG_ABL != 2
+    compute(smem + (kt & 1) * STAGE);
+#endif
   }
 
 #pragma unroll
-  for (int j = 0; j < NT_W; ++j) {
-    const int col = n0 + 32 * j + li;
+  for (int j = 0; j < T; ++j) {
+    const int col = n0 + BNW * wn + 16 * j + r16;
     if (col >= N) continue;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < M) C[(size_t)row * ldc + col] = acc[j][r] * s_out;
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 32 * wm + 16 * i + 4 * c4 + r;
+#if PG_ABL == 3
+        if (row < M && acc[i][j][r] == 12345.f) C[(size_t)row * ldc + col] = acc[i][j][r] * s_out;
+#else
+        if (row < M) C[(size_t)row * ldc + col] = acc[i][j][r] * s_out;
+#endif
+      }
   }
 }
 
@@ -343,33 +366,58 @@ int launch_split_weight2(const float* W, int R, int C, int transpose, const floa
   return WGNN_OK;
 }
 
-int pgemm_nt_np(int N) { return cdiv_i(N, 160) * 160; }
+// NT tiling of N: nsl slices of 32T columns (T <= 14: two stages of (192 + 448) 128-byte rows are exactly the
+// CU's 160 KB of LDS), as few slices as possible and as narrow as they can be.
+static void nt_shape(int N, int& nsl, int& T) {
+  nsl = cdiv_i(N, 448);
+  T = cdiv_i(cdiv_i(N, nsl), 32);
+}
+int pgemm_nt_np(int N) {
+  int nsl, T;
+  nt_shape(N, nsl, T);
+  return nsl * 32 * T;
+}
+
+template <int T>
+static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
+                       int ldc, int N, const float* s_out, bool x3, int nsl, hipStream_t st) {
+  const int nm = cdiv_i(M, NT_BM);
+  const int grid = cdiv_i(nm, 8) * 8 * nsl;
+  const size_t smem = 2 * (size_t)(2 * NT_BM + 2 * 32 * T) * 64;
+  static std::atomic<unsigned long long> done{0}, done16{0};
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
+  const double fl = 2.0 * M * (double)N * Kp;
+  const double by = (x3 ? 4.0 : 2.0) * ((double)M * Kp + (double)Np * Kp) + 4.0 * (double)M * N;
+  static const std::string name = "pgemm_nt_kernel<" + std::to_string(T) + ">", name16 = "pgemm_nt_kernel<" + std::to_string(T) + ",f16>";
+  if (x3)
+    PROF_LAUNCH(name.c_str(), fl, by, st,
+                hipLaunchKernelGGL((pgemm_nt_kernel<T, true>), dim3(grid), dim3(64 * NT_WAVES), smem, st,
+                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np,
+                                   C, ldc, N, s_out, nm, nsl));
+  else
+    PROF_LAUNCH(name16.c_str(), fl, by, st,
+                hipLaunchKernelGGL((pgemm_nt_kernel<T, false>), dim3(grid), dim3(64 * NT_WAVES), smem, st,
+                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np,
+                                   C, ldc, N, s_out, nm, nsl));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
 
 // C[M][N] = s_out * A B^T.  A planes [M][lda] (Kp <= lda), B stage-major planes with Np = pgemm_nt_np(N) rows.
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
                     int ldc, int N, const float* s_out, bool x3, hipStream_t st) {
-  if (Kp % 32 != 0 || lda % 8 != 0 || Np % 160 != 0) return WGNN_ERR_SHAPE;
-  constexpr int NTW = 5;
-  const int nm = cdiv_i(M, 128), nslices = Np / 160;
-  const int grid = cdiv_i(nm, 8) * 8 * nslices;
-  const size_t smem = 2 * (size_t)(2 * 128 + 2 * 32 * NTW) * 64;
-  static std::atomic<unsigned long long> done{0}, done16{0};
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<NTW, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<NTW, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
-  const double fl = 2.0 * M * (double)N * Kp;
-  const double by = (x3 ? 4.0 : 2.0) * ((double)M * Kp + (double)Np * Kp) + 4.0 * (double)M * N;
-  if (x3)
-    PROF_LAUNCH("pgemm_nt_kernel<5>", fl, by, st,
-                hipLaunchKernelGGL((pgemm_nt_kernel<NTW, true>), dim3(grid), dim3(PT), smem, st, (const _Float16*)Ahi,
-                                   (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, C, ldc, N, s_out, nm,
-                                   nslices));
-  else
-    PROF_LAUNCH("pgemm_nt_kernel<5,f16>", fl, by, st,
-                hipLaunchKernelGGL((pgemm_nt_kernel<NTW, false>), dim3(grid), dim3(PT), smem, st, (const _Float16*)Ahi,
-                                   (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, C, ldc, N, s_out, nm,
-                                   nslices));
-  WGNN_CHECK_LAUNCH();
-  return WGNN_OK;
+  int nsl, T;
+  nt_shape(N, nsl, T);
+  if (Kp % 32 != 0 || lda % 8 != 0 || Np != nsl * 32 * T) return WGNN_ERR_SHAPE;
+  switch (T) {
+#define NT_CASE(t) \
+  case t: return launch_nt_t<t>(Ahi, Alo, lda, M, Kp, Bplanes, Np, C, ldc, N, s_out, x3, nsl, st);
+    NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5) NT_CASE(6) NT_CASE(7) NT_CASE(8) NT_CASE(9) NT_CASE(10)
+    NT_CASE(11) NT_CASE(12) NT_CASE(13) NT_CASE(14)
+#undef NT_CASE
+  }
+  return WGNN_ERR_SHAPE;
 }
 
 // partial[z][Mout][Nout] = sum over k chunk z of A[k][m] B[k][n].  A planes [K][lda], B planes [K][ldb].
