@@ -53,8 +53,8 @@ Layout make_layout(const wgnn_dims* d) {
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
   L.stash_floats = o;
   if (x3) {
-    L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 160) * cdiv_i((int)L.I + 1, 128), 512, 64);
-    L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 160) * cdiv_i((int)L.H + 1, 128), 512, 64);
+    L.sk_ih = pick_splitk(L.BT, pgemm_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64);   // one workgroup per CU
+    L.sk_hh = pick_splitk(L.BT, pgemm_tn_tiles((int)L.G3, (int)L.H + 1), 256, 64);
   } else {
     L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128), 1024, 256);
     L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128), 1024, 256);

@@ -120,6 +120,7 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const fl
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
                          int Rp, int Cp, hipStream_t st);
 int pgemm_nt_np(int N);
+int pgemm_tn_tiles(int Mout, int Nout);   // output tiles per K chunk (sizes the split-K factor)
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
                     int ldc, int N, const float* s_out, bool x3, hipStream_t st);
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,

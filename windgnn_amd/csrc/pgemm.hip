@@ -6,15 +6,11 @@
 //                                                       dg = dGI W_ih
 //   TN  P[z][Mo][No]   = sum_k A[k][m] * B[k][n]        dW_ih = dGI^T [g|1], dW_hh = dGH^T [Hprev|1]
 //
-// Both kernels use 4-wave workgroups sized so that TWO workgroups share a CU (<= 80 KB LDS,
-// <= 256 VGPRs): with one 8-wave workgroup per CU every wave is in the same phase at the same time
-// and load / LDS-write / MFMA / epilogue phases simply add up (measured); two independent
-// workgroups overlap them.
-//
-// NT fragments are K-contiguous rows (ds_read_b128, 64-B rows XOR-swizzled by (row>>2)&3).
-// TN operands are K-strided in memory, so tiles are staged row-major [k][cols] exactly as they lie
-// in HBM and the MFMA fragments are formed by ds_read_b64_tr_b16 (hardware transpose read); the row
-// stride of 320 B (== 64 mod 256) makes the 4 rows x 64 B touched by a half-wave conflict-free.
+// Both kernels stage their operands with LDS-DMA (global_load_lds_dwordx4, swizzle applied on the
+// source address) into a two-stage ring and run ONE large workgroup per CU: these kernels sit at the
+// MFMA rate the chip sustains on real data (its clock drops to ~1.45 GHz under this load), and at
+// that clock the CU's L2 -> LDS path is the co-limiter, so tiles are as large as LDS allows to
+// minimise the bytes staged per MFMA.  All MFMAs are v_mfma_f32_16x16x32_f16.
 #include <string>
 
 #include "common.h"
@@ -28,14 +24,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define PG_ABL 0
 #endif
 namespace {
-
-constexpr int PT = 256;   // 4 waves
-
-__device__ __forceinline__ int sw_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
-
-__device__ __forceinline__ f32x16 mfma_h(h8 a, h8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
 
 // ------------------------------------------------------------------------------------------------
 // NT.  One 12-wave workgroup per CU owns a 192 x 32T tile: waves 6 (M) x 2 (N), wave tile 32 x 16T
@@ -186,148 +174,180 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
 }
 
 // ------------------------------------------------------------------------------------------------
-// TN.  BM = 32*MT_W columns of A (every wave), BN = 128 columns of B (wave w owns 32w..32w+31).
-// grid = (splitk, nMblocks * nNblocks): blocks with the same z and different tiles differ by a
-// multiple of splitk in linear id; splitk is a multiple of 8, so they share an XCD's L2.
-template <int MT_W, bool X3>
-__global__ void __launch_bounds__(PT, 2) pgemm_tn_kernel(const _Float16* __restrict__ Ahi,
-                                                         const _Float16* __restrict__ Alo, int lda,
-                                                         const _Float16* __restrict__ Bhi,
-                                                         const _Float16* __restrict__ Blo, int ldb, int shift_T,
-                                                         int K, int kchunk, float* __restrict__ partial, int Mout,
-                                                         int Nout, int nNb) {
-  constexpr int BM = 32 * MT_W, BN = 128;
-  constexpr int RS = 320;                                   // LDS row stride in bytes (== 64 mod 256)
-  constexpr int ACH = BM / 8, BCH = BN / 8;                 // 16-byte chunks per tile row
-  constexpr int PLANE = 32 * RS, STAGE = 4 * PLANE;         // Ahi, Alo, Bhi, Blo
-  constexpr int PL = X3 ? 2 : 1;                           // planes staged: hi (+ lo)
-  constexpr int NA = (PL * 32 * ACH + PT - 1) / PT, NB = (PL * 32 * BCH + PT - 1) / PT;
-  static_assert(BM * 2 <= RS && BN * 2 <= RS, "tile rows must fit the LDS row stride");
+// TN.  One 8-wave workgroup per CU owns a 320 x 32T tile of P for one K chunk: waves 4 (M) x 2 (N),
+// wave tile 80 x 16T of v_mfma_f32_16x16x32_f16.  Both operands are K-strided in memory, so a stage
+// (32 k rows) is staged row-major by LDS-DMA exactly as it lies in HBM and the fragments are formed
+// by ds_read_b64_tr_b16 (hardware transpose read).  The MFMA's k slots of lane group x are rows
+// {4x..4x+3} and {16+4x..16+4x+3} of the stage (any bijection works as long as A and B agree), so
+// one transpose read of a half-wave touches 8 consecutive rows x 32 B; the 32-byte segments of a row
+// are XOR-swizzled by g(row) (applied on the DMA source address) so that those 8 pieces fall into the
+// 8 different 32-byte bank groups whatever the row length.
+constexpr int TN_BM = 320, TN_WAVES = 8;
+
+__device__ __forceinline__ int tn_g(int stride32, int r) {   // stride32 = row bytes / 32 (even)
+  const int u = stride32 & 7;
+  return u == 0 ? (r & 7) : (u == 4 ? ((r >> 1) & 3) : ((r >> 2) & 1));
+}
+
+template <int T, bool X3>
+__global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16* __restrict__ Ahi,
+                                                                const _Float16* __restrict__ Alo, int lda,
+                                                                const _Float16* __restrict__ Bhi,
+                                                                const _Float16* __restrict__ Blo, int ldb,
+                                                                int shift_T, int K, int kchunk,
+                                                                float* __restrict__ partial, int Mout, int Nout,
+                                                                int nNb) {
+  constexpr int BM = TN_BM, BN = 32 * T;
+  constexpr int ARB = BM * 2, BRB = BN * 2;                         // row bytes
+  constexpr int A_PL = 32 * ARB, B_PL = 32 * BRB, STAGE = 2 * A_PL + 2 * B_PL;
+  constexpr int PL = X3 ? 2 : 1;                                   // planes moved: hi (+ lo)
+  constexpr int AP = A_PL / 1024, BP = B_PL / 1024;                // 1 KB pieces per plane
+  constexpr int NPIECE = PL * (AP + BP), NIT = (NPIECE + TN_WAVES - 1) / TN_WAVES;
+  constexpr int ACH = ARB / 16, BCH = BRB / 16;                    // 16-byte chunks per row
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
   const int z = blockIdx.x;
   const int mb = blockIdx.y / nNb, nb = blockIdx.y % nNb;
   const int m0 = mb * BM, n0 = nb * BN;
   const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
+  const int nk = kend > kbeg ? (kend - kbeg + 31) / 32 : 0;
 
-  f32x16 acc[MT_W];
+  f32x4 acc[5][T];
 #pragma unroll
-  for (int i = 0; i < MT_W; ++i)
+  for (int i = 0; i < 5; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int j = 0; j < T; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging maps: chunk q -> (plane, k row, 16-B column chunk)
-  int a_row[NA], a_col[NA], a_dst[NA];
-  bool a_on[NA], a_lo[NA];
+  // ---- staging map: piece p = wave + 8*it; lane-linear chunk q of a plane's stage image is (row q / CH,
+  // position q % CH) and receives source chunk position ^ 2 g(row)
+  const _Float16* base[NIT];
+  int ld[NIT], dst[NIT], prow[NIT], pcol[NIT];
+  bool on[NIT], isb[NIT];
 #pragma unroll
-  for (int it = 0; it < NA; ++it) {
-    const int q = tid + PT * it;
-    a_on[it] = q < PL * 32 * ACH;
-    const int qq = a_on[it] ? q : 0;
-    const int plane = qq / (32 * ACH), rem = qq % (32 * ACH);
-    a_lo[it] = plane != 0;
-    a_row[it] = rem / ACH;
-    a_col[it] = m0 + 8 * (rem % ACH);
-    a_on[it] = a_on[it] && a_col[it] < lda;                 // planes are padded to multiples of 8 columns
-    a_dst[it] = plane * PLANE + a_row[it] * RS + 16 * (rem % ACH);
+  for (int it = 0; it < NIT; ++it) {
+    const int p = wave + TN_WAVES * it;
+    on[it] = p < NPIECE;                                            // wave-uniform
+    const int pp = on[it] ? p : 0;
+    isb[it] = pp >= PL * AP;
+    if (!isb[it]) {
+      const int plane = pp / AP, q = 64 * (pp % AP) + lane;
+      const int row = q / ACH, pos = q % ACH;
+      const int col = m0 + 8 * (pos ^ (2 * tn_g(ARB / 32, row)));
+      base[it] = plane ? Alo : Ahi;
+      ld[it] = lda;
+      prow[it] = row;
+      pcol[it] = col < lda ? col : 0;                              // columns past the planes: any finite data
+      dst[it] = plane * A_PL + (pp % AP) * 1024;
+    } else {
+      const int q2 = pp - PL * AP;
+      const int plane = q2 / BP, q = 64 * (q2 % BP) + lane;
+      const int row = q / BCH, pos = q % BCH;
+      const int col = n0 + 8 * (pos ^ (2 * tn_g(BRB / 32, row)));
+      base[it] = plane ? Blo : Bhi;
+      ld[it] = ldb;
+      prow[it] = row;
+      pcol[it] = col < ldb ? col : 0;
+      dst[it] = 2 * A_PL + plane * B_PL + (q2 % BP) * 1024;
+    }
   }
-  int b_row[NB], b_col[NB], b_dst[NB];
-  bool b_on[NB], b_lo[NB];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  auto dma_stage = [&](char* st, int k0) {
 #pragma unroll
-  for (int it = 0; it < NB; ++it) {
-    const int q = tid + PT * it;
-    b_on[it] = q < PL * 32 * BCH;
-    const int qq = b_on[it] ? q : 0;
-    const int plane = qq / (32 * BCH), rem = qq % (32 * BCH);
-    b_lo[it] = plane != 0;
-    b_row[it] = rem / BCH;
-    b_col[it] = n0 + 8 * (rem % BCH);
-    b_on[it] = b_on[it] && b_col[it] < ldb;
-    b_dst[it] = (2 + plane) * PLANE + b_row[it] * RS + 16 * (rem % BCH);
-  }
-  u32x4 ra[NA], rb[NB];
-  const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int it = 0; it < NIT; ++it)
+      if (on[it]) {
+        int k = min(k0 + prow[it], kend - 1);                      // rows past the chunk: zeroed in LDS below
+        if (isb[it] && shift_T > 0) k = (k % shift_T) != 0 ? k - 1 : K;   // row K = the stored t = 0 row
+        __builtin_amdgcn_global_load_lds((glb_void*)(base[it] + (size_t)k * ld[it] + pcol[it]),
+                                         (lds_void*)(st + dst[it]), 16, 0, 0);
+      }
+  };
 
-#define TN_LOAD(k0)                                                                                  \
-  do {                                                                                               \
-    _Pragma("unroll") for (int it = 0; it < NA; ++it) {                                              \
-      const int k = (k0) + a_row[it];                                                                \
-      const bool ok = a_on[it] && k < kend;                                                          \
-      const u32x4 v = *(const u32x4*)((a_lo[it] ? Alo : Ahi) + (size_t)(ok ? k : kbeg) * lda + (ok ? a_col[it] : 0)); \
-      ra[it] = ok ? v : zero;                                                                        \
-    }                                                                                                \
-    _Pragma("unroll") for (int it = 0; it < NB; ++it) {                                              \
-      const int k = (k0) + b_row[it];                                                                \
-      const bool ok = b_on[it] && k < kend;                                                          \
-      int kr = k;                                                                                    \
-      if (shift_T > 0) kr = (k % shift_T) != 0 ? k - 1 : K;   /* row K = the stored t = 0 row */     \
-      const u32x4 v = *(const u32x4*)((b_lo[it] ? Blo : Bhi) + (size_t)(ok ? kr : kbeg) * ldb + (ok ? b_col[it] : 0)); \
-      rb[it] = ok ? v : zero;                                                                        \
-    }                                                                                                \
-  } while (0)
-#define TN_STORE(st)                                                                                 \
-  do {                                                                                               \
-    _Pragma("unroll") for (int it = 0; it < NA; ++it) if (tid + PT * it < PL * 32 * ACH) *(u32x4*)((st) + a_dst[it]) = ra[it]; \
-    _Pragma("unroll") for (int it = 0; it < NB; ++it) if (tid + PT * it < PL * 32 * BCH) *(u32x4*)((st) + b_dst[it]) = rb[it]; \
-  } while (0)
-
-  const int nk = (kend - kbeg + 31) / 32;
-  if (nk > 0) {
-    TN_LOAD(kbeg);
-    TN_STORE(smem);
-  }
-  __syncthreads();
-  // transpose-read addressing: 16-lane group x = lane>>4 handles 16 columns (x&1) and k-half (x>>1);
-  // inside a group lane 4q+p supplies the address of row q, columns 4p..4p+3 (8 bytes).
+  // ---- transpose-read addressing: lane 16x + 4q + p supplies row 4x + q, bytes 8p..8p+7 of the tile's
+  // 32-byte segment (second read: 16 rows further down)
   const int x = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const int tr_base = (8 * (x >> 1) + q4) * RS + (16 * (x & 1) + 4 * p4) * 2;
+  const int r1 = 4 * x + q4;
+  const int gA = 2 * tn_g(ARB / 32, r1), gB = 2 * tn_g(BRB / 32, r1);
+  int a_off[5], b_off[T];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) a_off[i] = r1 * ARB + 16 * ((2 * (5 * wm + i) + (p4 >> 1)) ^ gA) + 8 * (p4 & 1);
+#pragma unroll
+  for (int j = 0; j < T; ++j)
+    b_off[j] = 2 * A_PL + r1 * BRB + 16 * ((2 * (T * wn + j) + (p4 >> 1)) ^ gB) + 8 * (p4 & 1);
   typedef __attribute__((address_space(3))) fh4 lds_fh4;
-  auto trread = [&](const char* tile, int koff, int coff) -> h8 {
-    const char* p0 = tile + tr_base + koff * RS + coff * 2;
+  auto trread = [&](const char* p0, int rb) -> h8 {
     const fh4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fh4*)p0);
-    const fh4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fh4*)(p0 + 4 * RS));
+    const fh4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fh4*)(p0 + 16 * rb));
     const h4 w0 = __builtin_bit_cast(h4, v0), w1 = __builtin_bit_cast(h4, v1);
     h8 r;
     r[0] = w0[0]; r[1] = w0[1]; r[2] = w0[2]; r[3] = w0[3];
     r[4] = w1[0]; r[5] = w1[1]; r[6] = w1[2]; r[7] = w1[3];
     return r;
   };
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * STAGE;
-    const bool more = kt + 1 < nk;
-    if (more) TN_LOAD(kbeg + 32 * (kt + 1));
+  auto compute = [&](const char* cur) {
+    h8 ah[5], al[5];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const h8 bh = trread(cur + 2 * PLANE, 16 * ks, 32 * wave);
-      h8 bl = bh;
-      if (X3) bl = trread(cur + 3 * PLANE, 16 * ks, 32 * wave);
-#pragma unroll
-      for (int i = 0; i < MT_W; ++i) {
-        const h8 ah = trread(cur, 16 * ks, 32 * i);
-        if (X3) {
-          const h8 al = trread(cur + PLANE, 16 * ks, 32 * i);
-          acc[i] = mfma_h(al, bh, acc[i]);
-          acc[i] = mfma_h(ah, bl, acc[i]);
-        }
-        acc[i] = mfma_h(ah, bh, acc[i]);
-      }
+    for (int i = 0; i < 5; ++i) {
+      ah[i] = trread(cur + a_off[i], ARB);
+      al[i] = ah[i];
+      if (X3) al[i] = trread(cur + A_PL + a_off[i], ARB);
     }
-    if (more) TN_STORE(smem + ((kt + 1) & 1) * STAGE);
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      const h8 bh = trread(cur + b_off[j], BRB);
+      if (X3) {
+        const h8 bl = trread(cur + B_PL + b_off[j], BRB);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          acc[i][j] = mfma_q(al[i], bh, acc[i][j]);
+          acc[i][j] = mfma_q(ah[i], bl, acc[i][j]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) acc[i][j] = mfma_q(ah[i], bh, acc[i][j]);
+    }
+  };
+
+  if (nk > 0) dma_stage(smem, kbeg);
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // all waves: stage kt visible, stage kt-1 no longer being read
+#if PG_ABL != 1
+    if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kbeg + 32 * (kt + 1));
+#endif
+    const int rows = kend - (kbeg + 32 * kt);
+    if (rows < 32) {                   // last, partial stage of the chunk: rows >= kend contribute nothing
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      for (int c = tid; c < (32 - rows) * ACH; c += 64 * TN_WAVES) {
+        *(u32x4*)(cur + rows * ARB + 16 * c) = zero;
+        if (X3) *(u32x4*)(cur + A_PL + rows * ARB + 16 * c) = zero;
+      }
+      __syncthreads();
+    }
+#if PG_ABL != 2
+    compute(cur);
+#endif
   }
-#undef TN_LOAD
-#undef TN_STORE
 
   float* P = partial + (size_t)z * Mout * Nout;
-  const int li = lane & 31, lh = lane >> 5;
-  const int col = n0 + 32 * wave + li;
-  if (col < Nout) {
+  const int r16 = lane & 15, c4 = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < MT_W; ++i)
+  for (int j = 0; j < T; ++j) {
+    const int n = n0 + 16 * (T * wn + j) + r16;
+    if (n >= Nout) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < Mout) P[(size_t)row * Nout + col] = acc[i][r];
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 80 * wm + 16 * i + 4 * c4 + r;
+#if PG_ABL == 3
+        if (m < Mout && acc[i][j][r] == 12345.f) P[(size_t)m * Nout + n] = acc[i][j][r];
+#else
+        if (m < Mout) P[(size_t)m * Nout + n] = acc[i][j][r];
+#endif
       }
   }
 }
@@ -420,31 +440,57 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
   return WGNN_ERR_SHAPE;
 }
 
+// TN tiling: M blocks of 320, N blocks of 32T columns (T <= 7), as few as possible and as narrow as they can be.
+static void tn_shape(int Nout, int& nNb, int& T) {
+  nNb = cdiv_i(Nout, 224);
+  T = cdiv_i(cdiv_i(Nout, nNb), 32);
+}
+int pgemm_tn_tiles(int Mout, int Nout) {
+  int nNb, T;
+  tn_shape(Nout, nNb, T);
+  return cdiv_i(Mout, TN_BM) * nNb;
+}
+
+template <int T>
+static int launch_tn_t(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
+                       int K, int splitk, float* partial, int Mout, int Nout, bool x3, int nNb, hipStream_t st) {
+  const int nMb = cdiv_i(Mout, TN_BM);
+  const int kchunk = cdiv_i(cdiv_i(K, splitk), 32) * 32;
+  const size_t smem = 2 * (size_t)(2 * 32 * 2 * (TN_BM + 32 * T));
+  static std::atomic<unsigned long long> done{0}, done16{0};
+  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
+  const double fl = 2.0 * Mout * (double)Nout * K;
+  const double by = (x3 ? 4.0 : 2.0) * ((double)K * Mout + (double)K * Nout) + 4.0 * (double)splitk * Mout * Nout;
+  static const std::string name = "pgemm_tn_kernel<" + std::to_string(T) + ">",
+                           name16 = "pgemm_tn_kernel<" + std::to_string(T) + ",f16>";
+  if (x3)
+    PROF_LAUNCH(name.c_str(), fl, by, st,
+                hipLaunchKernelGGL((pgemm_tn_kernel<T, true>), dim3(splitk, nMb * nNb), dim3(64 * TN_WAVES), smem, st,
+                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
+                                   (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
+  else
+    PROF_LAUNCH(name16.c_str(), fl, by, st,
+                hipLaunchKernelGGL((pgemm_tn_kernel<T, false>), dim3(splitk, nMb * nNb), dim3(64 * TN_WAVES), smem, st,
+                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
+                                   (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
 // partial[z][Mout][Nout] = sum over k chunk z of A[k][m] B[k][n].  A planes [K][lda], B planes [K][ldb].
 // shift_T > 0: B row k is taken from row k-1, and from the extra row K (which the producer fills with what the
 // operand looks like at a window start) where k % shift_T == 0.
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
                     int K, int splitk, float* partial, int Mout, int Nout, bool x3, hipStream_t st) {
-  if (lda % 8 != 0 || ldb % 8 != 0) return WGNN_ERR_SHAPE;
-  constexpr int MTW = 5;
-  const int nMb = cdiv_i(Mout, 32 * MTW), nNb = cdiv_i(Nout, 128);
-  const int kchunk = cdiv_i(cdiv_i(K, splitk), 32) * 32;
-  const size_t smem = 2 * 4 * 32 * 320;
-  static std::atomic<unsigned long long> done{0}, done16{0};
-  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<MTW, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<MTW, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
-  const double fl = 2.0 * Mout * (double)Nout * K;
-  const double by = (x3 ? 4.0 : 2.0) * ((double)K * Mout + (double)K * Nout) + 4.0 * (double)splitk * Mout * Nout;
-  if (x3)
-    PROF_LAUNCH("pgemm_tn_kernel<5>", fl, by, st,
-                hipLaunchKernelGGL((pgemm_tn_kernel<MTW, true>), dim3(splitk, nMb * nNb), dim3(PT), smem, st,
-                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
-                                   (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
-  else
-    PROF_LAUNCH("pgemm_tn_kernel<5,f16>", fl, by, st,
-                hipLaunchKernelGGL((pgemm_tn_kernel<MTW, false>), dim3(splitk, nMb * nNb), dim3(PT), smem, st,
-                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
-                                   (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
-  WGNN_CHECK_LAUNCH();
-  return WGNN_OK;
+  if (lda % 8 != 0 || ldb % 8 != 0 || K < 1) return WGNN_ERR_SHAPE;
+  int nNb, T;
+  tn_shape(Nout, nNb, T);
+  switch (T) {
+#define TN_CASE(t) \
+  case t: return launch_tn_t<t>(Ahi, Alo, lda, Bhi, Blo, ldb, shift_T, K, splitk, partial, Mout, Nout, x3, nNb, st);
+    TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(7)
+#undef TN_CASE
+  }
+  return WGNN_ERR_SHAPE;
 }
