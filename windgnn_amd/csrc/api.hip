@@ -61,6 +61,10 @@ Layout make_layout(const wgnn_dims* d) {
   }
   size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
   size_t part_hh = (size_t)L.sk_hh * L.G3 * (L.H + 1);
+  if (x3) {
+    part_ih = pgemm_tn_partial_floats((int)L.G3, (int)L.I + 1, L.sk_ih);
+    part_hh = pgemm_tn_partial_floats((int)L.G3, (int)L.H + 1, L.sk_hh);
+  }
   o = 0;
   L.ws_dGI = o; o += al(L.BT * L.Gp);   // fp32, or hi+lo fp16 planes (same bytes)
   L.ws_dGH = o; o += al(L.BT * L.Gp);
@@ -218,15 +222,15 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
       rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
                            L.sk_hh, part, (int)L.G3, (int)L.H + 1, full, st);
       if (rc != WGNN_OK) return rc;
-      rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
-                                st);
+      rc = launch_pgemm_tn_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
+                                  st);
       if (rc != WGNN_OK) return rc;
       // dW_ih | db_ih = dGI^T [g | 1]
       rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part,
                            (int)L.G3, (int)L.I + 1, full, st);
       if (rc != WGNN_OK) return rc;
-      rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales,
-                                st);
+      rc = launch_pgemm_tn_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales,
+                                  st);
       if (rc != WGNN_OK) return rc;
     }   // the four GRU gradients are final here: a data-parallel caller can start reducing them now
     if (!do_gcn) return WGNN_OK;

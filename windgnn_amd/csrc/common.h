@@ -121,6 +121,9 @@ int launch_split_weight2(const float* W, int R, int C, int transpose, const floa
                          int Rp, int Cp, hipStream_t st);
 int pgemm_nt_np(int N);
 int pgemm_tn_tiles(int Mout, int Nout);   // output tiles per K chunk (sizes the split-K factor)
+size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk);
+int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
+                           float* bias_out, const float* scales, hipStream_t st);
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
                     int ldc, int N, const float* s_out, bool x3, hipStream_t st);
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,

@@ -332,23 +332,61 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
 #endif
   }
 
-  float* P = partial + (size_t)z * Mout * Nout;
-  const int r16 = lane & 15, c4 = lane >> 4;
+  // Partials are stored in the accumulators' own layout, [z][tile][wave][i][j][lane][4]: every store is a
+  // full 1 KB wave-instruction (row-major P would be 64-byte segments, 4x the store instructions);
+  // tn_reduce_kernel undoes the permutation while it sums over z.
+  float* P = partial + (((size_t)z * gridDim.y + blockIdx.y) * TN_WAVES + wave) * (5 * T * 256) + lane * 4;
 #pragma unroll
-  for (int j = 0; j < T; ++j) {
-    const int n = n0 + 16 * (T * wn + j) + r16;
-    if (n >= Nout) continue;
+  for (int i = 0; i < 5; ++i)
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 80 * wm + 16 * i + 4 * c4 + r;
+    for (int j = 0; j < T; ++j) {
 #if PG_ABL == 3
-        if (m < Mout && acc[i][j][r] == 12345.f) P[(size_t)m * Nout + n] = acc[i][j][r];
-#else
-        if (m < Mout) P[(size_t)m * Nout + n] = acc[i][j][r];
+      if (acc[i][j][0] == 12345.f)
 #endif
-      }
+      *(f32x4*)(P + (i * T + j) * 256) = acc[i][j];
+    }
+}
+
+// C[m][n] (and the bias column) = scale * sum_z partial[z][...] for partials in pgemm_tn_kernel's layout; the
+// summation tree over z is fixed, so the result is deterministic.  Four threads (z phases) per accumulator quad.
+__global__ void tn_reduce_kernel(const float* __restrict__ partial, int splitk, int T, int nNb, int ntiles, int Mout,
+                                 int Nout, float* __restrict__ C, int ldc, int ncols_main,
+                                 float* __restrict__ bias_out, const float* __restrict__ scales) {
+  const size_t slab4 = (size_t)ntiles * TN_WAVES * 5 * T * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 quads x 4 z phases per block
+  const size_t q = (size_t)blockIdx.x * 64 + tx;                     // slab4 is a multiple of 64
+  const f32x4* src = (const f32x4*)partial + q;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int z = ty;
+  for (; z + 12 < splitk; z += 16) {       // 4 independent 16-byte loads in flight per thread
+    s0 += src[(size_t)z * slab4];
+    s1 += src[(size_t)(z + 4) * slab4];
+    s2 += src[(size_t)(z + 8) * slab4];
+    s3 += src[(size_t)(z + 12) * slab4];
+  }
+  for (; z < splitk; z += 4) s0 += src[(size_t)z * slab4];
+  __shared__ f32x4 red[4][64];
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty != 0) return;
+  f32x4 s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (scales) s *= scales[1];
+  size_t t = q;
+  const int lane = (int)(t % 64); t /= 64;
+  const int j = (int)(t % T); t /= T;
+  const int i = (int)(t % 5); t /= 5;
+  const int wave = (int)(t % TN_WAVES);
+  const int tile = (int)(t / TN_WAVES);
+  const int mb = tile / nNb, nb = tile % nNb, wm = wave & 3, wn = wave >> 2;
+  const int n = nb * 32 * T + 16 * (T * wn + j) + (lane & 15);
+  const int m0 = mb * TN_BM + 80 * wm + 16 * i + 4 * (lane >> 4);
+  if (n >= Nout) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + r;
+    if (m >= Mout) continue;
+    if (n < ncols_main) C[(size_t)m * ldc + n] = s[r];
+    else if (bias_out && n == Nout - 1) bias_out[m] = s[r];
   }
 }
 
@@ -478,7 +516,28 @@ static int launch_tn_t(const void* Ahi, const void* Alo, int lda, const void* Bh
   return WGNN_OK;
 }
 
-// partial[z][Mout][Nout] = sum over k chunk z of A[k][m] B[k][n].  A planes [K][lda], B planes [K][ldb].
+size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk) {
+  int nNb, T;
+  tn_shape(Nout, nNb, T);
+  return (size_t)splitk * cdiv_i(Mout, TN_BM) * nNb * TN_WAVES * 5 * T * 256;
+}
+
+// C[Mout][ldc] columns [0, ncols_main) and bias_out (column Nout-1) = scales[1] * sum over z of launch_pgemm_tn's partials.
+int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
+                           float* bias_out, const float* scales, hipStream_t st) {
+  int nNb, T;
+  tn_shape(Nout, nNb, T);
+  const int ntiles = cdiv_i(Mout, TN_BM) * nNb;
+  const size_t slab4 = (size_t)ntiles * TN_WAVES * 5 * T * 64;
+  PROF_LAUNCH("tn_reduce_kernel", (double)slab4 * 4 * splitk, 16.0 * slab4 * splitk + 4.0 * Mout * Nout, st,
+              hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(slab4 / 64)), dim3(256), 0, st, partial,
+                                 splitk, T, nNb, ntiles, Mout, Nout, C, ldc, ncols_main, bias_out, scales));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+// partial (layout private to this file, pgemm_tn_partial_floats floats) = per-K-chunk sums of A[k][m] B[k][n].
+// A planes [K][lda], B planes [K][ldb].
 // shift_T > 0: B row k is taken from row k-1, and from the extra row K (which the producer fills with what the
 // operand looks like at a window start) where k % shift_T == 0.
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
