@@ -23,7 +23,7 @@ S, T, F, H = 34, 24, 13, 102
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
 # which roofline bounds each kernel (DESIGN.md "Kernels")
-BOUND_HBM_PREFIXES = ("mse_", "adam_", "amax_", "splitk_reduce", "split_weight", "gcn_partial")
+BOUND_HBM_PREFIXES = ("mse_", "adam_", "amax_", "splitk_reduce", "tn_reduce", "split_weight", "gcn_partial", "csr_", "gru_cell")
 
 
 def measured_traffic(kernel):
@@ -44,11 +44,17 @@ def adjacency_34():
     return torch.from_numpy(z["A34"]).float()          # src/main.py:26: float64 -> .float()
 
 
-def make_inputs(B, rank, dev):
+def make_inputs(B, rank, dev, S=S, H=H):
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.rand(B, T, S, F, generator=g)
     L = torch.rand(B, T, H, generator=g)
     return X.to(dev), L.to(dev)
+
+
+def adjacency_knn(S, k=8):
+    """BASELINE configs[4] / SURVEY 8d: S points over the station list's span, symmetric k-NN, CSR, seed 7."""
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    return CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=7), k))
 
 
 def host_threads():
@@ -98,8 +104,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="windows per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU (weak scaling); default 4096 (128 for c5)")
     ap.add_argument("--math", default="f16x3", choices=["f32", "f16x3", "f16"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+                    help="c3: 34 stations, the headline config; c5: 4096-station k-NN CSR stress config (exact fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,11 +129,14 @@ def main():
     from windgnn_amd.trainer import TrainStep
 
     torch.manual_seed(0)                                # identical parameters on every rank
+    S, H = (34, 102) if args.workload == "c3" else (4096, 12288)
+    if args.workload == "c5":
+        args.math = "f32"                               # CSR / wide-GRU shapes compute in exact fp32
+    B = args.batch or (4096 if args.workload == "c3" else 128)
     model = GCN_GRU(F, F, F, S * F, H, math=args.math).to(dev)
     trainer = TrainStep(model)
-    A = adjacency_34().to(dev)
-    B = args.batch
-    X, L = make_inputs(B, rank, dev)
+    A = (adjacency_34() if args.workload == "c3" else adjacency_knn(S)).to(dev)
+    X, L = make_inputs(B, rank, dev, S, H)
 
     def barrier():
         if world > 1:
@@ -201,7 +212,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "windows/sec (fwd+bwd) 34-node seq24 GCN-GRU",
+            "metric": "windows/sec (fwd+bwd) %s seq24 GCN-GRU" % ("34-node" if args.workload == "c3" else "4096-node"),
             "value": round(world * B * args.steps / dt, 1),
             "unit": "windows/s",
             "n_gpus": world,
@@ -213,15 +224,16 @@ def main():
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f16x3": "f16x3(split-fp32)", "f16": "f16"}[args.math],
             "data": "synthetic",
-            "config": {"workload": "S=34 stations, T=24, F=13, H=102, B=%d windows/GPU; step = forward + MSE + "
-                                   "backward + grad all-reduce (N>1) + Adam; fp32 I/O" % B,
+            "config": {"workload": "S=%d stations%s, T=24, F=13, H=%d, B=%d windows/GPU; step = forward + MSE + "
+                                   "backward + grad all-reduce (N>1) + Adam; fp32 I/O"
+                                   % (S, "" if args.workload == "c3" else " (symmetric 8-NN graph, CSR)", H, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "math": args.math},
             "loss": round(float(loss), 6),
             "roofline": roofline,
             "forward": forward,
             "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

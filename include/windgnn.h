@@ -18,7 +18,7 @@
  *   - Every data pointer is DEVICE memory owned by the caller (workspace and stash included);
  *     the library allocates nothing persistent, keeps no mutable global state, frees nothing.
  *   - All tensors are contiguous fp32 in the reference's layouts:
- *       A [S,S] row-major, X [B,T,S,F] (F fastest), Y [B,T,H], L [B,T,H],
+ *       A [S,S] row-major (or CSR, see wgnn_adj_format), X [B,T,S,F] (F fastest), Y [B,T,H], L [B,T,H],
  *       conv*.weight [F,F] (in,out), conv*.bias [F], w_ih [3H, S*F], w_hh [3H,H], b_ih/b_hh [3H],
  *       GRU gate row order r,z,n (torch nn.GRU).
  *   - Calls are asynchronous and ordered on `stream` (a hipStream_t passed as void*; NULL = the
@@ -44,7 +44,7 @@ typedef enum wgnn_status {
   WGNN_ERR_SHAPE = -2,       /* a dimension is <= 0 or outside what the kernels support */
   WGNN_ERR_DTYPE = -3,       /* unsupported dtype / math mode */
   WGNN_ERR_WORKSPACE = -4,   /* workspace or stash smaller than wgnn_*_bytes() says */
-  WGNN_ERR_UNSUPPORTED = -5, /* e.g. adjacency format not built yet */
+  WGNN_ERR_UNSUPPORTED = -5, /* e.g. a dense adjacency with S > 64 (pass it as CSR) */
   WGNN_ERR_HIP = -6          /* a HIP runtime call or kernel launch failed */
 } wgnn_status;
 
@@ -55,6 +55,14 @@ typedef enum wgnn_math {
   WGNN_MATH_F16 = 2    /* plain fp16 operands, one MFMA pass, fp32 accumulate: ~1e-3 error (16-bit config) */
 } wgnn_math;
 
+/* Adjacency argument `A` of wgnn_fwd / wgnn_bwd:
+ *   WGNN_ADJ_DENSE  A [S,S] fp32 row-major, S <= 64 (held in LDS);
+ *   WGNN_ADJ_CSR    any S: `A` points to ONE device buffer of 2*(S+1+2*nnz) 32-bit words holding the matrix
+ *                   and its transpose (the backward multiplies by A^T), each as
+ *                     rowptr int32[S+1] | col int32[nnz] (ascending inside a row) | val fp32[nnz]:
+ *                   words [0, S+1+2*nnz) describe A, the next S+1+2*nnz words describe A^T
+ *                   (windgnn_amd.graph.CsrAdjacency builds it).  CSR calls compute in exact fp32 whatever
+ *                   `math` says, as does any shape the fp16-plane kernels do not cover (H > 127). */
 typedef enum wgnn_adj_format { WGNN_ADJ_DENSE = 0, WGNN_ADJ_CSR = 1 } wgnn_adj_format;
 
 typedef struct wgnn_dims {
@@ -65,7 +73,7 @@ typedef struct wgnn_dims {
   int32_t H;          /* GRU hidden width (reference: 3*S) */
   int32_t math;       /* wgnn_math */
   int32_t adj_format; /* wgnn_adj_format */
-  int32_t nnz;        /* CSR only */
+  int32_t nnz;        /* CSR only: stored entries of A */
 } wgnn_dims;
 
 /* The 8 tensors of the reference state_dict, in its key order. */

@@ -5,6 +5,7 @@ import os
 import re
 
 import pytest
+import numpy as np
 import torch
 
 from conftest import PARAM_KEYS, ROOT, load_fixture
@@ -33,8 +34,13 @@ def test_dims_validation_no_gpu_needed():
     assert lib.wgnn_workspace_bytes(ctypes.byref(ok)) > 0
     assert lib.wgnn_stash_bytes(ctypes.byref(ok)) > 0
     for bad in (L.Dims(0, 24, 34, 13, 102, 0, 0, 0), L.Dims(4, 24, 34, 12, 102, 0, 0, 0),
-                L.Dims(4, 24, 4096, 13, 12288, 0, 1, 10)):
+                L.Dims(4, 24, 65, 13, 195, 0, 0, 0),           # dense adjacency beyond the LDS-resident path
+                L.Dims(4, 24, 4096, 13, 12288, 0, 1, 0),       # CSR without entries
+                L.Dims(4, 24, 34, 13, 102, 0, 2, 0)):          # unknown adjacency format
         assert lib.wgnn_workspace_bytes(ctypes.byref(bad)) == 0
+    c5 = L.Dims(128, 24, 4096, 13, 12288, 0, 1, 73000)        # BASELINE configs[4], one GPU's shard
+    assert lib.wgnn_workspace_bytes(ctypes.byref(c5)) > (1 << 32) and lib.wgnn_stash_bytes(ctypes.byref(c5)) > 0
+    assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4, 24, 34, 13, 400, 1, 0, 0))) > 0   # wide GRU: general path
     p = L.Params()
     rc = lib.wgnn_fwd(ctypes.byref(ok), None, None, ctypes.byref(p), None, None, None, 0, None)
     assert rc == -1 and b"NULL" in lib.wgnn_strerror(rc)
@@ -82,3 +88,32 @@ def test_build_graph_matches_reference_output():
     df = pd.DataFrame({"Station Name": ["s%d" % i for i in range(34)] * 2,
                        "Latitude": list(z["coords34"][:, 0]) * 2, "Longitude": list(z["coords34"][:, 1]) * 2})
     assert np.abs(build_graph(df) - z["A34"]).max() <= 1e-12      # duplicates dropped, first-appearance order
+
+
+def test_knn_csr_adjacency_host_logic():
+    """N1 (CSR emitter): symmetric k-NN sparsification of the reference's weights, normalised; the C-ABI blob
+    holds A and A^T."""
+    from windgnn_amd.graph import CsrAdjacency, build_adjacency, build_knn_adjacency, synthetic_station_coords
+    c = synthetic_station_coords(60, seed=3)
+    rp, col, val = build_knn_adjacency(c, 8)
+    csr = CsrAdjacency(rp, col, val)
+    D = csr.dense().double().numpy()
+    assert np.abs(D - D.T).max() < 1e-7                      # symmetric by construction
+    assert np.all(np.diag(D) > 0) and csr.nnz >= 60 * 9      # self loops + at least k neighbours per row
+    assert np.all(np.diff(rp) >= 9)
+    # with k = S-1 nothing is dropped: it must equal the reference's dense construction
+    rp2, col2, val2 = build_knn_adjacency(c, 59)
+    assert np.abs(CsrAdjacency(rp2, col2, val2).dense().double().numpy() - build_adjacency(c)).max() < 1e-6
+    # blob layout of include/windgnn.h: A then A^T, each rowptr | col | val
+    S, nnz = csr.S, csr.nnz
+    b = csr.blob.numpy()
+    assert b.shape[0] == 2 * (S + 1 + 2 * nnz)
+    t = b[S + 1 + 2 * nnz:]
+    trp, tcol, tval = t[:S + 1], t[S + 1:S + 1 + nnz], t[S + 1 + nnz:].view(np.float32)
+    DT = np.zeros((S, S), np.float32)
+    for r in range(S):
+        DT[r, tcol[trp[r]:trp[r + 1]]] = tval[trp[r]:trp[r + 1]]
+        assert np.all(np.diff(tcol[trp[r]:trp[r + 1]]) > 0)
+    assert np.abs(DT - D.T.astype(np.float32)).max() == 0.0
+    with pytest.raises(ValueError):
+        CsrAdjacency([0, 1], [5], [1.0])

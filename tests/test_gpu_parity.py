@@ -293,3 +293,105 @@ def test_f16_mode_within_its_stated_tolerance(fixture):
     assert ey > 1e-6          # sanity: this really is the 16-bit path, not the split one
     for k in PARAM_KEYS:
         assert rel_to_max(grads[k], fx["grads"][k]) <= F16_G_TOL, k
+
+
+# ---- general shapes: CSR adjacency (BASELINE configs[4]) and hidden widths beyond the fast kernels ----
+
+def _oracle_step(A, X, L, p):
+    from oracle import windgnn_oracle as orc
+    return orc.train_step(A.double(), X.double(), L.double(), {k: v.double() for k, v in p.items()})
+
+
+@pytest.mark.parametrize("S,T,B,H,k", [(34, 6, 5, 102, 4), (200, 3, 4, 60, 8), (300, 2, 3, 150, 8), (7, 4, 2, 21, 6)])
+def test_csr_adjacency_against_oracle(S, T, B, H, k):
+    """k-NN graph in CSR through wgnn_fwd / wgnn_bwd against the dense CPU oracle (S > 64 has no dense path)."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    dev = _dev()
+    csr = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=S), k))
+    A = csr.dense()
+    g = torch.Generator().manual_seed(77 + S)
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    p = orc.init_params(S, 13, H, seed=S + H)
+    Yo, loss_o, go = _oracle_step(A, X, L, p)
+    model = _model_from(p, S, H, "f32")
+    out, loss, grads = _run_step(model, csr.to(dev), X.to(dev), L.to(dev))
+    assert max_abs(out.reshape(Yo.shape), Yo) <= Y_TOL
+    assert abs(loss - float(loss_o)) <= 1e-5 * max(1.0, float(loss_o))
+    for key in PARAM_KEYS:
+        assert rel_to_max(grads[key], go[key]) <= G_TOL, key
+    with torch.no_grad():                                    # inference: no stash (src/main.py:100-102)
+        out2 = model(csr, X.to(dev))
+    assert max_abs(out2.cpu().reshape(Yo.shape), Yo) <= Y_TOL
+
+
+def test_csr_of_the_34_station_graph_matches_the_dense_path():
+    """The same adjacency handed over dense and as CSR gives the same result (fp32 family, different kernels)."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.graph import CsrAdjacency
+    dev = _dev()
+    import os
+    from conftest import GOLDEN
+    A = torch.from_numpy(np.load(os.path.join(GOLDEN, "graph_7_34.npz"))["A34"]).float()   # reference build_graph output
+    S, T, B, H = 34, 24, 8, 102
+    g = torch.Generator().manual_seed(3)
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    p = orc.init_params(S, 13, H, seed=1)
+    model = _model_from(p, S, H, "f32")
+    out_d, loss_d, grads_d = _run_step(model, A.to(dev), X.to(dev), L.to(dev))
+    out_c, loss_c, grads_c = _run_step(model, CsrAdjacency.from_dense(A).to(dev), X.to(dev), L.to(dev))
+    assert max_abs(out_c, out_d) <= 1e-5
+    for key in PARAM_KEYS:
+        assert rel_to_max(grads_c[key], grads_d[key]) <= 1e-5, key
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("S,T,B,H", [(20, 5, 6, 200), (34, 3, 4, 130)])
+def test_wide_hidden_state_against_oracle(S, T, B, H, math):
+    """gru_hidden_dim is a free constructor argument (src/step6_gcn_gru_combined_model.py:7): widths beyond the
+    register-resident recurrence kernels take the per-step GEMM path (exact fp32 whatever `math` asks for)."""
+    from oracle import windgnn_oracle as orc
+    dev = _dev()
+    g = torch.Generator().manual_seed(500 + H)
+    A = torch.rand(S, S, generator=g) / S + 0.01
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    p = orc.init_params(S, 13, H, seed=H)
+    Yo, loss_o, go = _oracle_step(A, X, L, p)
+    model = _model_from(p, S, H, math)
+    out, loss, grads = _run_step(model, A.to(dev), X.to(dev), L.to(dev))
+    assert max_abs(out.reshape(Yo.shape), Yo) <= Y_TOL
+    for key in PARAM_KEYS:
+        assert rel_to_max(grads[key], go[key]) <= G_TOL, key
+
+
+def test_dense_adjacency_beyond_64_stations_is_refused():
+    from oracle import windgnn_oracle as orc
+    dev = _dev()
+    S, H = 65, 12
+    model = _model_from(orc.init_params(S, 13, H, seed=0), S, H, "f32")
+    with pytest.raises(RuntimeError, match="not supported"):
+        model(torch.rand(S, S).to(dev), torch.rand(1, 2, S, 13).to(dev))
+
+
+def test_4096_station_csr_config_full_width_stations():
+    """BASELINE configs[4] graph (4096-station symmetric 8-NN, CSR) at full S with a narrow GRU so that the CPU
+    oracle stays small: exercises the SpMM kernels, the 53 248-wide input projection and its gradients."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    dev = _dev()
+    S, T, B, H = 4096, 2, 2, 24
+    csr = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=7), 8))
+    A = csr.dense()
+    g = torch.Generator().manual_seed(4096)
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    p = orc.init_params(S, 13, H, seed=9)
+    Yo, loss_o, go = _oracle_step(A, X, L, p)
+    model = _model_from(p, S, H, "f32")
+    out, loss, grads = _run_step(model, csr.to(dev), X.to(dev), L.to(dev))
+    assert max_abs(out.reshape(Yo.shape), Yo) <= Y_TOL
+    for key in PARAM_KEYS:
+        assert rel_to_max(grads[key], go[key]) <= G_TOL, key

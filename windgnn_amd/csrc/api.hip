@@ -17,6 +17,11 @@ struct Layout {
   // backward workspace
   size_t ws_dGI, ws_dGH, ws_dg, ws_part, ws_gcnpart, ws_planes_b, ws_scales, bwd_floats;
   int sk_ih, sk_hh;
+  // which kernels run: the fp16-plane family needs the dense LDS-resident GCN and the register-resident GRU;
+  // shapes beyond the fast kernels (CSR adjacency, wide hidden state) use general.hip in exact fp32
+  bool x3, gen_gcn, gen_gru;
+  size_t st_h1;                                  // general GCN: layer-1 activations
+  size_t ws_gh, ws_h1, ws_du, ws_dhz, ws_dhw;    // general GRU / GCN scratch
 };
 
 int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
@@ -29,7 +34,11 @@ int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
 
 Layout make_layout(const wgnn_dims* d) {
   Layout L;
-  const bool x3 = d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16;   // the fp16-plane kernel family
+  L.gen_gcn = d->adj_format == WGNN_ADJ_CSR;
+  L.gen_gru = d->math == WGNN_MATH_F32 ? !gru_shape_supported(d->H) : !grux_shape_supported(d->H);
+  if (L.gen_gcn) L.gen_gru = L.gen_gru || !gru_shape_supported(d->H);   // CSR runs the f32 family
+  L.x3 = d->math != WGNN_MATH_F32 && !L.gen_gcn && !L.gen_gru;          // the fp16-plane kernel family
+  const bool x3 = L.x3;
   L.BT = (size_t)d->B * d->T;
   L.I = (size_t)d->S * d->F;
   L.Ip = rup(L.I + (x3 ? 1 : 0), 32);       // f16x3: room for the ones column at index I
@@ -46,11 +55,14 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_GI = o; o += al(L.BT * L.Gp);   // rows padded to 128-B multiples
   L.ws_g = o; o += al(L.BT * L.Ip);    // fp32 g (f32 mode) or its two fp16 planes (f16x3): same bytes
   L.ws_planes_f = o; o += al(planes_f);
+  L.ws_gh = o; o += al(L.gen_gru ? (size_t)d->B * L.G3 : 0);
+  L.ws_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
   L.st_gates = o; o += al(L.BT * 4 * L.H);
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
+  L.st_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.stash_floats = o;
   if (x3) {
     L.sk_ih = pick_splitk(L.BT, pgemm_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64);   // one workgroup per CU
@@ -72,8 +84,12 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_part = o; o += al(part_ih > part_hh ? part_ih : part_hh);
   {
     size_t a = gcn2_bwd_partial_floats((int)L.BT), b = gcnx2_bwd_partial_floats((int)L.BT);
+    if (L.gen_gcn) a = gcn_csr_bwd_partial_floats();
     L.ws_gcnpart = o; o += al(a > b ? a : b);
   }
+  L.ws_du = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
+  L.ws_dhz = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
+  L.ws_dhw = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
   L.ws_planes_b = o; o += al(planes_b);
   L.ws_scales = o; o += al(512);
   L.bwd_floats = o;
@@ -85,11 +101,18 @@ int check_dims(const wgnn_dims* d) {
   if (d->B < 1 || d->T < 1 || d->S < 1 || d->H < 1) return WGNN_ERR_SHAPE;
   if (d->F != 13) return WGNN_ERR_SHAPE;            // the reference hard-codes 13 (step6:16)
   if ((int64_t)d->B * d->T > (1 << 30)) return WGNN_ERR_SHAPE;
-  if (d->adj_format != WGNN_ADJ_DENSE) return WGNN_ERR_UNSUPPORTED;
-  if (d->S > 64) return WGNN_ERR_UNSUPPORTED;       // dense LDS-resident adjacency path
-  if (d->math == WGNN_MATH_F32 && !gru_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
   if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3 && d->math != WGNN_MATH_F16) return WGNN_ERR_DTYPE;
-  if (d->math != WGNN_MATH_F32 && !grux_shape_supported(d->H)) return WGNN_ERR_UNSUPPORTED;
+  if (d->adj_format == WGNN_ADJ_CSR) {
+    if (d->nnz < 1 || (int64_t)d->nnz > (int64_t)d->S * d->S) return WGNN_ERR_SHAPE;
+  } else if (d->adj_format == WGNN_ADJ_DENSE) {
+    if (d->S > 64) return WGNN_ERR_UNSUPPORTED;     // dense adjacency is the LDS-resident path; larger graphs: CSR
+  } else {
+    return WGNN_ERR_UNSUPPORTED;
+  }
+  // 32-bit element counts inside the kernels: one weight matrix / one activation matrix must stay below 2^31
+  if ((int64_t)3 * d->H * d->S * d->F >= (1ll << 31) || (int64_t)3 * d->H * d->H >= (1ll << 31)) return WGNN_ERR_SHAPE;
+  if ((int64_t)d->B * d->T * d->S * d->F >= (1ll << 31) || (int64_t)d->B * d->T * 4 * d->H >= (1ll << 31))
+    return WGNN_ERR_SHAPE;
   return WGNN_OK;
 }
 
@@ -107,7 +130,7 @@ const char* wgnn_strerror(int status) {
     case WGNN_ERR_DTYPE: return "unsupported dtype / math mode";
     case WGNN_ERR_WORKSPACE: return "workspace or stash too small";
     case WGNN_ERR_UNSUPPORTED:
-      return "configuration not supported by this build (dense S <= 64; H <= 110 in f32 mode, <= 127 in f16x3)";
+      return "configuration not supported by this build (a dense adjacency needs S <= 64: pass larger graphs as CSR)";
     case WGNN_ERR_HIP: return "HIP runtime error (kernel launch failed)";
     default: return "unknown status";
   }
@@ -140,7 +163,7 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   float* GI = ws + L.ws_GI;
   float* g = sf ? sf + L.st_g : ws + L.ws_g;
   float* gates = sf ? sf + L.st_gates : nullptr;
-  const bool x3 = d->math != WGNN_MATH_F32;          // fp16-plane kernels
+  const bool x3 = L.x3;                              // fp16-plane kernels
   const bool full = d->math == WGNN_MATH_F16X3;      // three-pass split products (false: one fp16 pass)
 
   if (x3) {
@@ -158,8 +181,14 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
                            full, st);
   }
-  rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                       (int)L.Ip, st);
+  if (L.gen_gcn) {
+    float* h1 = sf ? sf + L.st_h1 : ws + L.ws_h1;    // layer-1 activations: kept for the backward if there is a stash
+    rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight,
+                             p->conv2_bias, h1, g, L.Ip, st);
+  } else {
+    rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
+                         (int)L.Ip, st);
+  }
   if (rc != WGNN_OK) return rc;
   GemmArgs ga = {};
   ga.A = g; ga.lda = (int)L.Ip; ga.a_kcontig = 1;
@@ -168,6 +197,8 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   ga.bias = p->b_ih; ga.splitk = 1;
   rc = launch_gemm_f32(ga, st);
   if (rc != WGNN_OK) return rc;
+  if (L.gen_gru)
+    return launch_gru_gen_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, ws + L.ws_gh, st);
   return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, st);
 }
 
@@ -200,7 +231,7 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
   float* dg = ws + L.ws_dg;
   float* part = ws + L.ws_part;
   float* scales = ws + L.ws_scales;          // [0] = 2^k, [1] = 2^-k (f16x3 range scaling), then 256 partials
-  const bool x3 = d->math != WGNN_MATH_F32;
+  const bool x3 = L.x3;
   const bool full = d->math == WGNN_MATH_F16X3;
 
   if (x3) {
@@ -248,7 +279,11 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
   }
 
   if (do_rec) {
-    rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
+    if (L.gen_gru)
+      rc = launch_gru_gen_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, ws + L.ws_dhz,
+                              ws + L.ws_dhw, st);
+    else
+      rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;
   }
   if (do_wg) {
@@ -283,6 +318,10 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     rc = launch_gemm_f32(c, st);
     if (rc != WGNN_OK) return rc;
   }
+  if (L.gen_gcn)
+    return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, gact, L.Ip, dg, L.I,
+                               ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias, g->conv2_weight,
+                               g->conv2_bias, st);
   return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                          g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);
 }

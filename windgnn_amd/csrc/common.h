@@ -128,6 +128,17 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
                     int ldc, int N, const float* s_out, bool x3, hipStream_t st);
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
                     int K, int splitk, float* partial, int Mout, int Nout, bool x3, hipStream_t st);
+// general shapes (general.hip): CSR adjacency (blob layout: see include/windgnn.h) and any hidden width
+size_t gcn_csr_bwd_partial_floats();
+int launch_gcn2_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W1, const float* b1,
+                        const float* W2, const float* b2, float* h1, float* g, size_t ldg, hipStream_t st);
+int launch_gcn2_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W2, const float* h1,
+                        const float* g, size_t ldg, const float* dg, size_t ld_dg, float* du, float* partial,
+                        float* dW1, float* db1, float* dW2, float* db2, hipStream_t st);
+int launch_gru_gen_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                       float* gates, float* gh, hipStream_t st);
+int launch_gru_gen_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
+                       float* dGI, float* dGH, int ldd, float* dhz, float* dhw, hipStream_t st);
 int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W,
                     const float* b, float* out, hipStream_t st);
 size_t gcn1_bwd_partial_floats(int ntiles);

@@ -1,0 +1,279 @@
+// General-shape kernels: everything the LDS/register-resident fast kernels do not cover.
+//
+//   * CSR adjacency (BASELINE config 5: 4096-station k-NN graph): the two GraphConvLayers
+//     relu((A X) W + b)  (src/step5_gcn_layer_model.py:15,18,21) with A X as a row-gather SpMM, and
+//     their backward, which needs A^T products and therefore the transposed CSR too.
+//   * GRU recurrences of any hidden width (src/step6_gcn_gru_combined_model.py:23): per timestep one
+//     fp32 MFMA GEMM (gemm.hip) for gh = W_hh h + b_hh / dh += dgh W_hh and one elementwise cell kernel.
+//
+// All arithmetic is fp32 in a fixed order (deterministic).  At these sizes the step is dominated by
+// the W_ih / W_hh GEMMs (45 TFLOP per step per GPU at config 5 against 6 GFLOP of SpMM), so the SpMM
+// kernels are written for clarity: one thread per (tile, station) row, 13 accumulators in registers,
+// neighbour rows gathered from L2 (a tile's X is 213 KB at S = 4096).
+#include "common.h"
+
+namespace {
+
+constexpr int F13 = 13;
+constexpr int FP = 16;
+constexpr int PART = 2 * FP * FP + 2 * FP;   // same partial layout as gcn.hip: dW1 | dW2 | db1 | db2
+constexpr int ROWS = 256;                    // stations per block
+constexpr int GEN_BLOCKS = 1024;             // persistent backward blocks = partial rows
+
+struct Csr {
+  const int* rowptr;
+  const int* col;
+  const float* val;
+};
+
+// p[f] = sum_e val[e] * V[col[e]][f] over row s, in CSR order
+__device__ __forceinline__ void spmv_row(const Csr& c, int s, const float* __restrict__ V, float (&p)[F13]) {
+#pragma unroll
+  for (int f = 0; f < F13; ++f) p[f] = 0.f;
+  const int e1 = c.rowptr[s + 1];
+  for (int e = c.rowptr[s]; e < e1; ++e) {
+    const float v = c.val[e];
+    const float* x = V + (size_t)c.col[e] * F13;
+#pragma unroll
+    for (int f = 0; f < F13; ++f) p[f] = fmaf(v, x[f], p[f]);
+  }
+}
+
+// Out[tile][s][:] = relu((A In[tile])[s][:] W + b)
+__global__ void __launch_bounds__(ROWS) csr_layer_fwd_kernel(int ntiles, int S, Csr A, const float* __restrict__ In,
+                                                             size_t ld_in, const float* __restrict__ W,
+                                                             const float* __restrict__ b, float* __restrict__ Out,
+                                                             size_t ld_out) {
+  __shared__ float Ws[F13 * F13], bs[F13];
+  for (int i = threadIdx.x; i < F13 * F13; i += ROWS) Ws[i] = W[i];
+  if (threadIdx.x < F13) bs[threadIdx.x] = b[threadIdx.x];
+  __syncthreads();
+  const int s = blockIdx.x * ROWS + threadIdx.x;
+  if (s >= S) return;
+  for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+    float p[F13];
+    spmv_row(A, s, In + (size_t)tile * ld_in, p);
+    float* o = Out + (size_t)tile * ld_out + (size_t)s * F13;
+#pragma unroll
+    for (int c = 0; c < F13; ++c) {
+      float a = bs[c];
+#pragma unroll
+      for (int f = 0; f < F13; ++f) a = fmaf(p[f], Ws[f * F13 + c], a);
+      o[c] = fmaxf(a, 0.f);
+    }
+  }
+}
+
+// One backward layer for a block's share of (tile, row-block) items:
+//   dz = dOut * (Out > 0)           where dOut is given directly (layer 2: dg) or as A^T DU (layer 1)
+//   p  = (A In)[s]                  (recomputed aggregation)
+//   dW += p^T dz, db += dz          (per-block partials, fixed order)
+//   DU[tile][s][:] = dz W^T         (layer 2 only: what layer 1's A^T product consumes)
+template <bool LAYER2>
+__global__ void __launch_bounds__(ROWS) csr_layer_bwd_kernel(int ntiles, int S, Csr A, Csr AT,
+                                                             const float* __restrict__ In, size_t ld_in,
+                                                             const float* __restrict__ Out, size_t ld_out,
+                                                             const float* __restrict__ dOut, size_t ld_dout,
+                                                             const float* __restrict__ W, float* __restrict__ DU,
+                                                             float* __restrict__ partial) {
+  __shared__ float Ws[F13 * F13];
+  __shared__ float ps[ROWS][F13], dzs[ROWS][F13];
+  const int tid = threadIdx.x;
+  if (LAYER2)
+    for (int i = tid; i < F13 * F13; i += ROWS) Ws[i] = W[i];
+  const int nrb = (S + ROWS - 1) / ROWS;
+  const long long nitems = (long long)ntiles * nrb;
+  // thread t < 169: dW[t/13][t%13]; 169 <= t < 182: db[t-169].  fp64: these are long sums of mixed-sign terms
+  // (cancellation ~100x at S = 4096) and the loop is far off the critical path.
+  double acc = 0.0;
+  for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int tile = (int)(item / nrb), s = (int)(item % nrb) * ROWS + tid;
+    float p[F13], dz[F13];
+    if (s < S) {
+      const float* o = Out + (size_t)tile * ld_out + (size_t)s * F13;
+      if (LAYER2) {
+        const float* d = dOut + (size_t)tile * ld_dout + (size_t)s * F13;
+#pragma unroll
+        for (int f = 0; f < F13; ++f) dz[f] = o[f] > 0.f ? d[f] : 0.f;
+      } else {
+        spmv_row(AT, s, dOut + (size_t)tile * ld_dout, dz);   // dH1 = A^T DU
+#pragma unroll
+        for (int f = 0; f < F13; ++f) dz[f] = o[f] > 0.f ? dz[f] : 0.f;
+      }
+      spmv_row(A, s, In + (size_t)tile * ld_in, p);
+    } else {
+#pragma unroll
+      for (int f = 0; f < F13; ++f) p[f] = dz[f] = 0.f;
+    }
+    __syncthreads();   // previous item's outer product is done (and Ws is loaded)
+#pragma unroll
+    for (int f = 0; f < F13; ++f) {
+      ps[tid][f] = p[f];
+      dzs[tid][f] = dz[f];
+    }
+    if (LAYER2 && s < S) {
+      float* du = DU + ((size_t)tile * S + s) * F13;
+#pragma unroll
+      for (int f = 0; f < F13; ++f) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < F13; ++c) a = fmaf(dz[c], Ws[f * F13 + c], a);
+        du[f] = a;
+      }
+    }
+    __syncthreads();
+    if (tid < F13 * F13) {
+      const int f = tid / F13, c = tid % F13;
+      for (int r = 0; r < ROWS; ++r) acc += (double)ps[r][f] * (double)dzs[r][c];
+    } else if (tid < F13 * F13 + F13) {
+      const int c = tid - F13 * F13;
+      for (int r = 0; r < ROWS; ++r) acc += (double)dzs[r][c];
+    }
+  }
+  float* mine = partial + (size_t)blockIdx.x * PART;
+  if (tid < F13 * F13) mine[(LAYER2 ? FP * FP : 0) + (tid / F13) * FP + tid % F13] = (float)acc;
+  else if (tid < F13 * F13 + F13) mine[2 * FP * FP + (LAYER2 ? FP : 0) + tid - F13 * F13] = (float)acc;
+}
+
+// ---- GRU cell, forward: one thread per (window, hidden unit) -----------------------------------
+__global__ void gru_cell_fwd_kernel(int B, int T, int t, int H, const float* __restrict__ GI, int ldgi,
+                                    const float* __restrict__ GH, int ldgh, const float* __restrict__ bhh,
+                                    float* __restrict__ Y, float* __restrict__ gates) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * H) return;
+  const int b = (int)(i / H), j = (int)(i % H);
+  const size_t bt = (size_t)b * T + t;
+  const float* gi = GI + bt * ldgi;
+  float ghr, ghz, ghn, hprev = 0.f;
+  if (t == 0) {   // h0 = 0: gh = b_hh
+    ghr = bhh[j]; ghz = bhh[H + j]; ghn = bhh[2 * H + j];
+  } else {
+    const float* gh = GH + (size_t)b * ldgh;
+    ghr = gh[j]; ghz = gh[H + j]; ghn = gh[2 * H + j];
+    hprev = Y[(bt - 1) * H + j];
+  }
+  const float r = sigmoidf_(gi[j] + ghr);
+  const float z = sigmoidf_(gi[H + j] + ghz);
+  const float n = tanhf_(gi[2 * H + j] + r * ghn);
+  Y[bt * H + j] = (1.f - z) * n + z * hprev;
+  if (gates) {
+    float* gp = gates + bt * 4 * H;
+    gp[j] = r; gp[H + j] = z; gp[2 * H + j] = n; gp[3 * H + j] = ghn;
+  }
+}
+
+// backward cell: dh = dY_t + dhz + dhw (the two carries of step t+1)
+__global__ void gru_cell_bwd_kernel(int B, int T, int t, int H, const float* __restrict__ Y,
+                                    const float* __restrict__ dY, const float* __restrict__ gates,
+                                    float* __restrict__ dhz, const float* __restrict__ dhw, float* __restrict__ dGI,
+                                    float* __restrict__ dGH, int ldd) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * H) return;
+  const int b = (int)(i / H), j = (int)(i % H);
+  const size_t bt = (size_t)b * T + t;
+  float dh = dY[bt * H + j];
+  if (t < T - 1) dh += dhz[i] + (dhw ? dhw[i] : 0.f);
+  const float* gp = gates + bt * 4 * H;
+  const float r = gp[j], z = gp[H + j], n = gp[2 * H + j], ghn = gp[3 * H + j];
+  const float hprev = t > 0 ? Y[(bt - 1) * H + j] : 0.f;
+  const float dn = dh * (1.f - z);
+  const float dzg = dh * (hprev - n);
+  const float dnt = dn * (1.f - n * n);
+  const float dr = dnt * ghn;
+  const float dar = dr * r * (1.f - r);
+  const float daz = dzg * z * (1.f - z);
+  float* gi = dGI + bt * ldd;
+  float* gh = dGH + bt * ldd;
+  gi[j] = dar; gi[H + j] = daz; gi[2 * H + j] = dnt;
+  gh[j] = dar; gh[H + j] = daz; gh[2 * H + j] = dnt * r;
+  dhz[i] = dh * z;
+}
+
+Csr csr_of(const void* blob, int S, int nnz, bool transposed) {
+  const int* w = (const int*)blob + (transposed ? (size_t)S + 1 + 2 * (size_t)nnz : 0);
+  Csr c;
+  c.rowptr = w;
+  c.col = w + S + 1;
+  c.val = (const float*)(w + S + 1 + nnz);
+  return c;
+}
+
+}  // namespace
+
+size_t gcn_csr_bwd_partial_floats() { return (size_t)GEN_BLOCKS * PART; }
+
+int launch_gcn2_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W1, const float* b1,
+                        const float* W2, const float* b2, float* h1, float* g, size_t ldg, hipStream_t st) {
+  const Csr A = csr_of(csr, S, nnz, false);
+  const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
+  const double fl = (double)ntiles * (2.0 * nnz * F13 + 2.0 * S * F13 * F13), by = (double)ntiles * S * F13 * 8.0;
+  const size_t I = (size_t)S * F13;
+  PROF_LAUNCH("csr_layer_fwd_kernel", fl, by, st,
+              hipLaunchKernelGGL(csr_layer_fwd_kernel, grid, dim3(ROWS), 0, st, ntiles, S, A, X, I, W1, b1, h1, I));
+  WGNN_CHECK_LAUNCH();
+  PROF_LAUNCH("csr_layer_fwd_kernel", fl, by, st,
+              hipLaunchKernelGGL(csr_layer_fwd_kernel, grid, dim3(ROWS), 0, st, ntiles, S, A, h1, I, W2, b2, g, ldg));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+// dW1, db1, dW2, db2 of the two layers given dg; du: scratch [ntiles][S*13]; partial: gcn_csr_bwd_partial_floats()
+int launch_gcn2_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W2, const float* h1,
+                        const float* g, size_t ldg, const float* dg, size_t ld_dg, float* du, float* partial,
+                        float* dW1, float* db1, float* dW2, float* db2, hipStream_t st) {
+  const Csr A = csr_of(csr, S, nnz, false), AT = csr_of(csr, S, nnz, true);
+  const size_t I = (size_t)S * F13;
+  const double fl = (double)ntiles * (2.0 * nnz * F13 + 4.0 * S * F13 * F13), by = (double)ntiles * S * F13 * 16.0;
+  PROF_LAUNCH("csr_layer_bwd_kernel<2>", fl, by, st,
+              hipLaunchKernelGGL((csr_layer_bwd_kernel<true>), dim3(GEN_BLOCKS), dim3(ROWS), 0, st, ntiles, S, A, AT, h1,
+                                 I, g, ldg, dg, ld_dg, W2, du, partial));
+  WGNN_CHECK_LAUNCH();
+  PROF_LAUNCH("csr_layer_bwd_kernel<1>", fl + (double)ntiles * 2.0 * nnz * F13, by, st,
+              hipLaunchKernelGGL((csr_layer_bwd_kernel<false>), dim3(GEN_BLOCKS), dim3(ROWS), 0, st, ntiles, S, A, AT, X,
+                                 I, h1, I, du, I, (const float*)nullptr, (float*)nullptr, partial));
+  WGNN_CHECK_LAUNCH();
+  return launch_gcn_partial_reduce(partial, GEN_BLOCKS, dW1, db1, dW2, db2, st);
+}
+
+// Y, gates from GI: per step gh = Hprev W_hh^T + b_hh (GEMM, skipped at t = 0 where h = 0) and the cell.
+int launch_gru_gen_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                       float* gates, float* gh /*[B][3H]*/, hipStream_t st) {
+  const int nb = (int)(((long long)B * H + 255) / 256);
+  for (int t = 0; t < T; ++t) {
+    if (t > 0) {
+      GemmArgs a = {};
+      a.A = Y + (size_t)(t - 1) * H; a.lda = T * H; a.a_kcontig = 1;     // row b = h_{t-1} of window b
+      a.B = Whh; a.ldb = H; a.b_kcontig = 1;
+      a.C = gh; a.ldc = 3 * H; a.M = B; a.N = 3 * H; a.K = H;
+      a.bias = bhh; a.splitk = 1;
+      int rc = launch_gemm_f32(a, st);
+      if (rc != WGNN_OK) return rc;
+    }
+    PROF_LAUNCH("gru_cell_fwd_kernel", 0.0, (double)B * H * 4.0 * 9, st,
+                hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(nb), dim3(256), 0, st, B, T, t, H, GI, ldgi, gh, 3 * H, bhh,
+                                   Y, gates));
+    WGNN_CHECK_LAUNCH();
+  }
+  return WGNN_OK;
+}
+
+// dGI, dGH rows for all (b, t); dhz / dhw: scratch [B][H] each
+int launch_gru_gen_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
+                       float* dGI, float* dGH, int ldd, float* dhz, float* dhw, hipStream_t st) {
+  const int nb = (int)(((long long)B * H + 255) / 256);
+  for (int t = T - 1; t >= 0; --t) {
+    PROF_LAUNCH("gru_cell_bwd_kernel", 0.0, (double)B * H * 4.0 * 14, st,
+                hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(nb), dim3(256), 0, st, B, T, t, H, Y, dY, gates, dhz, dhw,
+                                   dGI, dGH, ldd));
+    WGNN_CHECK_LAUNCH();
+    if (t > 0) {   // dhw = dGH_t W_hh: the recurrent part of dh_{t-1}
+      GemmArgs a = {};
+      a.A = dGH + (size_t)t * ldd; a.lda = T * ldd; a.a_kcontig = 1;
+      a.B = Whh; a.ldb = H; a.b_kcontig = 0;
+      a.C = dhw; a.ldc = H; a.M = B; a.N = H; a.K = 3 * H; a.splitk = 1;
+      int rc = launch_gemm_f32(a, st);
+      if (rc != WGNN_OK) return rc;
+    }
+  }
+  return WGNN_OK;
+}

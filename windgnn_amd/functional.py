@@ -31,8 +31,15 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _dims(B, T, S, F, H, math):
-    return _lib.Dims(B, T, S, F, H, math, _lib.ADJ_DENSE, 0)
+def _adj(A):
+    """(device tensor to pass, adj_format, nnz) for a dense [S,S] tensor or a graph.CsrAdjacency."""
+    if hasattr(A, "blob"):                                    # CsrAdjacency
+        if not A.blob.is_cuda:
+            raise RuntimeError("windgnn_amd: the CSR adjacency is on %s; call .to(device) first (no CPU fallback)"
+                               % A.blob.device)
+        return A.blob, _lib.ADJ_CSR, A.nnz
+    _require_gpu(A)
+    return A.contiguous(), _lib.ADJ_DENSE, 0
 
 
 def _params_struct(cls, tensors: Sequence[torch.Tensor]):
@@ -59,10 +66,13 @@ class _Workspace:
 def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32, want_stash=True):
     """Y[B,T,H], stash = wgnn_fwd(...).  X is [B,T,S,F]."""
     lib = _lib.load()
-    _require_gpu(A, X, *params)
+    _require_gpu(X, *params)
+    A, fmt, nnz = _adj(A)
     B, T, S, F = X.shape
     H = params[5].shape[1]
-    d = _dims(B, T, S, F, H, math)
+    if fmt == _lib.ADJ_DENSE and tuple(A.shape) != (S, S):
+        raise RuntimeError("windgnn_amd: adjacency %s does not match %d stations" % (tuple(A.shape), S))
+    d = _lib.Dims(B, T, S, F, H, math, fmt, nnz)
     ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
     if ws_bytes == 0:
         _lib.check(-5 if F == 13 else -2, "wgnn_workspace_bytes(B=%d,T=%d,S=%d,F=%d,H=%d)" % (B, T, S, F, H))
@@ -78,6 +88,7 @@ def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32
 def gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, grads: Sequence[torch.Tensor], part: int = 7, stream=None):
     """part bit mask (wgnn_bwd_part): 1 = BPTT recurrence, 4 = GRU weight-gradient GEMMs, 2 = dg + GCN backward."""
     lib = _lib.load()
+    A = getattr(A, "blob", A)              # CsrAdjacency -> its device buffer (d.adj_format says which it is)
     ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
     ws = _Workspace.get(X.device, ws_bytes)
     ps = _params_struct(_lib.Params, params)
@@ -93,14 +104,13 @@ class GCNGRUFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, X, math, *params):
-        A = A.contiguous()
         X = X.contiguous()
         params = tuple(p.contiguous() for p in params)
         need = any(ctx.needs_input_grad[3:])
         Y, stash, d = gcn_gru_forward_raw(A, X, params, math, want_stash=need)
         ctx.d = d
         ctx.stash = stash
-        ctx.save_for_backward(A, X, Y, *params)
+        ctx.save_for_backward(_adj(A)[0], X, Y, *params)   # dense [S,S] or the CSR blob; d.adj_format says which
         return Y
 
     @staticmethod
