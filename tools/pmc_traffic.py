@@ -19,9 +19,12 @@ def short(n):
         ln = int(m.group(1))
         rest = n[m.end():]
         name, tail = rest[:ln], rest[ln:]
-        t = re.match(r"I((?:Li\d+E)+)E", tail)
+        t = re.match(r"I((?:L[ib]\d+E)+)E", tail)      # <int..., bool X3>: bench.py prints X3 = false as ",f16"
         if t:
-            return name + "<" + ",".join(re.findall(r"Li(\d+)E", t.group(1))) + ">"
+            args = re.findall(r"Li(\d+)E", t.group(1))
+            if "0" in re.findall(r"Lb(\d)E", t.group(1)):
+                args.append("f16")
+            return name + ("<" + ",".join(args) + ">" if args else "")
         return name
     n = n.split("(")[0]
     return re.sub(r"\s+", "", n)

@@ -20,9 +20,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __fp16 fh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef PG_ABL
-#define PG_ABL 0
-#endif
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -147,12 +144,8 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // all waves: stage kt visible, stage kt-1 no longer being read
-#if PG_ABL != 1
     if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kt + 1);
-#endif
-#if PG_ABL != 2
     compute(smem + (kt & 1) * STAGE);
-#endif
   }
 
 #pragma unroll
@@ -164,11 +157,7 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 32 * wm + 16 * i + 4 * c4 + r;
-#if PG_ABL == 3
-        if (row < M && acc[i][j][r] == 12345.f) C[(size_t)row * ldc + col] = acc[i][j][r] * s_out;
-#else
         if (row < M) C[(size_t)row * ldc + col] = acc[i][j][r] * s_out;
-#endif
       }
   }
 }
@@ -315,9 +304,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
     char* cur = smem + (kt & 1) * STAGE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // all waves: stage kt visible, stage kt-1 no longer being read
-#if PG_ABL != 1
     if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kbeg + 32 * (kt + 1));
-#endif
     const int rows = kend - (kbeg + 32 * kt);
     if (rows < 32) {                   // last, partial stage of the chunk: rows >= kend contribute nothing
       const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -327,9 +314,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
       }
       __syncthreads();
     }
-#if PG_ABL != 2
     compute(cur);
-#endif
   }
 
   // Partials are stored in the accumulators' own layout, [z][tile][wave][i][j][lane][4]: every store is a
@@ -340,9 +325,6 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
   for (int i = 0; i < 5; ++i)
 #pragma unroll
     for (int j = 0; j < T; ++j) {
-#if PG_ABL == 3
-      if (acc[i][j][0] == 12345.f)
-#endif
       *(f32x4*)(P + (i * T + j) * 256) = acc[i][j];
     }
 }
