@@ -61,8 +61,8 @@ typedef enum wgnn_math {
  *                   and its transpose (the backward multiplies by A^T), each as
  *                     rowptr int32[S+1] | col int32[nnz] (ascending inside a row) | val fp32[nnz]:
  *                   words [0, S+1+2*nnz) describe A, the next S+1+2*nnz words describe A^T
- *                   (windgnn_amd.graph.CsrAdjacency builds it).  CSR calls compute in exact fp32 whatever
- *                   `math` says, as does any shape the fp16-plane kernels do not cover (H > 127). */
+ *                   (windgnn_amd.graph.CsrAdjacency builds it).  The sparse aggregation itself is always
+ *                   exact fp32; `math` selects the kernels of the dense GRU contractions as usual. */
 typedef enum wgnn_adj_format { WGNN_ADJ_DENSE = 0, WGNN_ADJ_CSR = 1 } wgnn_adj_format;
 
 typedef struct wgnn_dims {

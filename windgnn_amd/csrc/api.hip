@@ -20,8 +20,9 @@ struct Layout {
   // which kernels run: the fp16-plane family needs the dense LDS-resident GCN and the register-resident GRU;
   // shapes beyond the fast kernels (CSR adjacency, wide hidden state) use general.hip in exact fp32
   bool x3, gen_gcn, gen_gru;
+  int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
   size_t st_h1;                                  // general GCN: layer-1 activations
-  size_t ws_gh, ws_h1, ws_du, ws_dhz, ws_dhw;    // general GRU / GCN scratch
+  size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_du, ws_dhz, ws_dhw, ws_hhp_b;   // general GRU / GCN scratch
 };
 
 int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
@@ -34,10 +35,9 @@ int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
 
 Layout make_layout(const wgnn_dims* d) {
   Layout L;
+  L.x3 = d->math != WGNN_MATH_F32;                                      // the fp16-plane kernel family
   L.gen_gcn = d->adj_format == WGNN_ADJ_CSR;
-  L.gen_gru = d->math == WGNN_MATH_F32 ? !gru_shape_supported(d->H) : !grux_shape_supported(d->H);
-  if (L.gen_gcn) L.gen_gru = L.gen_gru || !gru_shape_supported(d->H);   // CSR runs the f32 family
-  L.x3 = d->math != WGNN_MATH_F32 && !L.gen_gcn && !L.gen_gru;          // the fp16-plane kernel family
+  L.gen_gru = L.x3 ? !grux_shape_supported(d->H) : !gru_shape_supported(d->H);
   const bool x3 = L.x3;
   L.BT = (size_t)d->B * d->T;
   L.I = (size_t)d->S * d->F;
@@ -55,8 +55,11 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_GI = o; o += al(L.BT * L.Gp);   // rows padded to 128-B multiples
   L.ws_g = o; o += al(L.BT * L.Ip);    // fp32 g (f32 mode) or its two fp16 planes (f16x3): same bytes
   L.ws_planes_f = o; o += al(planes_f);
-  L.ws_gh = o; o += al(L.gen_gru ? (size_t)d->B * L.G3 : 0);
+  L.np_h = pgemm_nt_np((int)L.H);
+  L.ws_gh = o; o += al(L.gen_gru ? (size_t)d->B * L.Gp : 0);
   L.ws_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
+  L.ws_yp = o; o += al(L.gen_gru && x3 ? (L.BT + 1) * L.Hp : 0);            // h planes when there is no stash
+  L.ws_hhp_f = o; o += al(L.gen_gru && x3 ? (size_t)L.np_g3 * L.Hp : 0);    // split(W_hh | b_hh)
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
@@ -90,6 +93,7 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_du = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.ws_dhz = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
   L.ws_dhw = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
+  L.ws_hhp_b = o; o += al(L.gen_gru && x3 ? (size_t)L.np_h * L.Gp : 0);     // split(W_hh^T)
   L.ws_planes_b = o; o += al(planes_b);
   L.ws_scales = o; o += al(512);
   L.bwd_floats = o;
@@ -171,20 +175,31 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, (int)L.I, ws + L.ws_planes_f, L.np_g3,
                               (int)L.Ip, st);
     if (rc != WGNN_OK) return rc;
-    rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                          (int)L.Ip, full, st);
+    if (L.gen_gcn)    // CSR adjacency: fp32 SpMM layers, layer 2 writes the g planes
+      rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight,
+                               p->conv2_bias, sf ? sf + L.st_h1 : ws + L.ws_h1, nullptr, g, L.Ip, full, st);
+    else
+      rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
+                            (int)L.Ip, full, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
                          (int)L.Gp, (int)L.G3, nullptr, full, st);
     if (rc != WGNN_OK) return rc;
+    if (L.gen_gru) {  // any hidden width: one plane GEMM per step against split(W_hh | b_hh)
+      rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 0, p->b_hh, (int)L.H, ws + L.ws_hhp_f, L.np_g3, (int)L.Hp,
+                                st);
+      if (rc != WGNN_OK) return rc;
+      return launch_gru_gen_fwd_x3(d->B, d->T, d->H, GI, (int)L.Gp, ws + L.ws_hhp_f, L.np_g3, p->b_hh, Y, gates,
+                                   sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, full, st);
+    }
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
                            full, st);
   }
   if (L.gen_gcn) {
     float* h1 = sf ? sf + L.st_h1 : ws + L.ws_h1;    // layer-1 activations: kept for the backward if there is a stash
     rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight,
-                             p->conv2_bias, h1, g, L.Ip, st);
+                             p->conv2_bias, h1, g, nullptr, L.Ip, false, st);
   } else {
     rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
                          (int)L.Ip, st);
@@ -245,7 +260,14 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     if (do_rec) {
       rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
       if (rc != WGNN_OK) return rc;
-      rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
+      if (L.gen_gru) {
+        rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 1, nullptr, 0, ws + L.ws_hhp_b, L.np_h, (int)L.Gp, st);
+        if (rc != WGNN_OK) return rc;
+        rc = launch_gru_gen_bwd_x3(d->B, d->T, d->H, ws + L.ws_hhp_b, L.np_h, Y, dY, gates, scales, dGIh, dGHh,
+                                   (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, full, st);
+      } else {
+        rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
+      }
       if (rc != WGNN_OK) return rc;
     }
     if (do_wg) {
@@ -271,6 +293,10 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I,
                          (int)L.I, nullptr, full, st);
     if (rc != WGNN_OK) return rc;
+    if (L.gen_gcn)
+      return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
+                                 L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
+                                 g->conv2_weight, g->conv2_bias, st);
     rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                           scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, st);
     if (rc != WGNN_OK) return rc;
@@ -319,9 +345,9 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     if (rc != WGNN_OK) return rc;
   }
   if (L.gen_gcn)
-    return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, gact, L.Ip, dg, L.I,
-                               ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias, g->conv2_weight,
-                               g->conv2_bias, st);
+    return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, gact, nullptr, L.Ip, dg,
+                               L.I, nullptr, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
+                               g->conv2_weight, g->conv2_bias, st);
   return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                          g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);
 }

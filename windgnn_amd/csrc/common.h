@@ -131,10 +131,17 @@ int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, 
 // general shapes (general.hip): CSR adjacency (blob layout: see include/windgnn.h) and any hidden width
 size_t gcn_csr_bwd_partial_floats();
 int launch_gcn2_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W1, const float* b1,
-                        const float* W2, const float* b2, float* h1, float* g, size_t ldg, hipStream_t st);
+                        const float* W2, const float* b2, float* h1, float* g, void* g_planes, size_t ldg, bool x3,
+                        hipStream_t st);
 int launch_gcn2_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W2, const float* h1,
-                        const float* g, size_t ldg, const float* dg, size_t ld_dg, float* du, float* partial,
-                        float* dW1, float* db1, float* dW2, float* db2, hipStream_t st);
+                        const float* g, const void* g_hi, size_t ldg, const float* dg, size_t ld_dg,
+                        const float* scales, float* du, float* partial, float* dW1, float* db1, float* dW2, float* db2,
+                        hipStream_t st);
+int launch_gru_gen_fwd_x3(int B, int T, int H, const float* GI, int ldgi, const void* whh_planes, int np_g3,
+                          const float* bhh, float* Y, float* gates, void* y_planes, float* gh, bool x3, hipStream_t st);
+int launch_gru_gen_bwd_x3(int B, int T, int H, const void* whhT_planes, int np_h, const float* Y, const float* dY,
+                          const float* gates, const float* scales, void* dgi_planes, void* dgh_planes, int ldd,
+                          float* dhz, float* dhw, bool x3, hipStream_t st);
 int launch_gru_gen_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
                        float* gates, float* gh, hipStream_t st);
 int launch_gru_gen_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,

@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
                                                                 const _Float16* __restrict__ Alo, int lda, int M,
                                                                 int Kp, const _Float16* __restrict__ Bpl, int Np,
                                                                 float* __restrict__ C, int ldc, int N,
-                                                                const float* __restrict__ s_out_p, int nm, int nsl) {
+                                                                const float* __restrict__ s_out_p, int nm, int nsl,
+                                                                size_t bplane, int accumulate) {
   constexpr int BM = NT_BM, BNW = 16 * T, BN = 2 * BNW;
   constexpr int A_PL = BM * 64, B_PL = BN * 64, STAGE = 2 * A_PL + 2 * B_PL;
   constexpr int PL = X3 ? 2 : 1;                                   // planes moved: hi (+ lo)
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     } else {
       const int q = pp - PL * AP;
       const int plane = q / BP, blk = q % BP;
-      src[it] = Bpl + (size_t)plane * Np * Kp + (size_t)(n0 + 16 * blk + prow) * 32 + chunk;
+      src[it] = Bpl + (size_t)plane * bplane + (size_t)(n0 + 16 * blk + prow) * 32 + chunk;
       dst[it] = 2 * A_PL + plane * B_PL + blk * 1024;
       kadv[it] = Np * 32;
     }
@@ -157,7 +158,11 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 32 * wm + 16 * i + 4 * c4 + r;
-        if (row < M) C[(size_t)row * ldc + col] = acc[i][j][r] * s_out;
+        if (row < M) {
+          float* dst = C + (size_t)row * ldc + col;
+          const float v = acc[i][j][r] * s_out;
+          *dst = accumulate ? *dst + v : v;
+        }
       }
   }
 }
@@ -427,20 +432,29 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
   static std::atomic<unsigned long long> done{0}, done16{0};
   if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
   if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
-  const double fl = 2.0 * M * (double)N * Kp;
-  const double by = (x3 ? 4.0 : 2.0) * ((double)M * Kp + (double)Np * Kp) + 4.0 * (double)M * N;
   static const std::string name = "pgemm_nt_kernel<" + std::to_string(T) + ">", name16 = "pgemm_nt_kernel<" + std::to_string(T) + ",f16>";
-  if (x3)
-    PROF_LAUNCH(name.c_str(), fl, by, st,
-                hipLaunchKernelGGL((pgemm_nt_kernel<T, true>), dim3(grid), dim3(64 * NT_WAVES), smem, st,
-                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np,
-                                   C, ldc, N, s_out, nm, nsl));
-  else
-    PROF_LAUNCH(name16.c_str(), fl, by, st,
-                hipLaunchKernelGGL((pgemm_nt_kernel<T, false>), dim3(grid), dim3(64 * NT_WAVES), smem, st,
-                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np,
-                                   C, ldc, N, s_out, nm, nsl));
-  WGNN_CHECK_LAUNCH();
+  // Long contractions (the 4096-station projections: K = 53 248) run as 2048-wide K chunks accumulated in C:
+  // an fp32 accumulator chain of at most 64 MFMA steps per chunk keeps the summation error at fp32-GEMM level.
+  constexpr int KC = 2048;
+  const int nchunks = Kp > KC + KC / 2 ? cdiv_i(Kp, KC) : 1;
+  const size_t bplane = (size_t)Np * Kp;
+  for (int c = 0; c < nchunks; ++c) {
+    const int k0 = nchunks > 1 ? c * KC : 0, kc = nchunks > 1 ? (Kp - k0 < KC ? Kp - k0 : KC) : Kp;
+    const _Float16* ah = (const _Float16*)Ahi + k0;
+    const _Float16* al = (const _Float16*)Alo + k0;
+    const _Float16* bp = (const _Float16*)Bplanes + (size_t)(k0 / 32) * Np * 32;
+    const double fl = 2.0 * M * (double)N * kc;
+    const double by = (x3 ? 4.0 : 2.0) * ((double)M * kc + (double)Np * kc) + 4.0 * (double)M * N * (c > 0 ? 2 : 1);
+    if (x3)
+      PROF_LAUNCH(name.c_str(), fl, by, st,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true>), dim3(grid), dim3(64 * NT_WAVES), smem, st, ah, al, lda, M,
+                                     kc, bp, Np, C, ldc, N, s_out, nm, nsl, bplane, c > 0 ? 1 : 0));
+    else
+      PROF_LAUNCH(name16.c_str(), fl, by, st,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, false>), dim3(grid), dim3(64 * NT_WAVES), smem, st, ah, al, lda, M,
+                                     kc, bp, Np, C, ldc, N, s_out, nm, nsl, bplane, c > 0 ? 1 : 0));
+    WGNN_CHECK_LAUNCH();
+  }
   return WGNN_OK;
 }
 
