@@ -22,7 +22,7 @@ struct Layout {
   bool x3, gen_gcn, gen_gru;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
   size_t st_h1;                                  // general GCN: layer-1 activations
-  size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_du, ws_dhz, ws_dhw, ws_hhp_b;   // general GRU / GCN scratch
+  size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_kp_f, ws_hc, ws_du, ws_dhz, ws_dhw, ws_hhp_b, ws_kp_b, ws_dc;   // general GRU / GCN scratch
 };
 
 int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
@@ -60,6 +60,8 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.ws_yp = o; o += al(L.gen_gru && x3 ? (L.BT + 1) * L.Hp : 0);            // h planes when there is no stash
   L.ws_hhp_f = o; o += al(L.gen_gru && x3 ? (size_t)L.np_g3 * L.Hp : 0);    // split(W_hh | b_hh)
+  L.ws_kp_f = o; o += al(L.gen_gru && x3 ? pgemm_nt_kpart_floats(d->B, (int)L.Gp, (int)L.Hp) : 0);
+  L.ws_hc = o; o += al(L.gen_gru && x3 ? (size_t)d->B * L.Hp : 0);          // compact planes of h_{t-1}
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
@@ -94,6 +96,8 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_dhz = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
   L.ws_dhw = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
   L.ws_hhp_b = o; o += al(L.gen_gru && x3 ? (size_t)L.np_h * L.Gp : 0);     // split(W_hh^T)
+  L.ws_kp_b = o; o += al(L.gen_gru && x3 ? pgemm_nt_kpart_floats(d->B, (int)L.H, (int)L.Gp) : 0);
+  L.ws_dc = o; o += al(L.gen_gru && x3 ? (size_t)d->B * L.Gp : 0);          // compact planes of dgh_t
   L.ws_planes_b = o; o += al(planes_b);
   L.ws_scales = o; o += al(512);
   L.bwd_floats = o;
@@ -184,14 +188,15 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
-                         (int)L.Gp, (int)L.G3, nullptr, full, st);
+                         (int)L.Gp, (int)L.G3, nullptr, full, nullptr, st);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gru) {  // any hidden width: one plane GEMM per step against split(W_hh | b_hh)
       rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 0, p->b_hh, (int)L.H, ws + L.ws_hhp_f, L.np_g3, (int)L.Hp,
                                 st);
       if (rc != WGNN_OK) return rc;
       return launch_gru_gen_fwd_x3(d->B, d->T, d->H, GI, (int)L.Gp, ws + L.ws_hhp_f, L.np_g3, p->b_hh, Y, gates,
-                                   sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, full, st);
+                                   sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, ws + L.ws_kp_f, ws + L.ws_hc, full,
+                                   st);
     }
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
                            full, st);
@@ -264,7 +269,7 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
         rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 1, nullptr, 0, ws + L.ws_hhp_b, L.np_h, (int)L.Gp, st);
         if (rc != WGNN_OK) return rc;
         rc = launch_gru_gen_bwd_x3(d->B, d->T, d->H, ws + L.ws_hhp_b, L.np_h, Y, dY, gates, scales, dGIh, dGHh,
-                                   (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, full, st);
+                                   (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, ws + L.ws_kp_b, ws + L.ws_dc, full, st);
       } else {
         rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
       }
@@ -291,7 +296,7 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, ws + L.ws_planes_b, L.np_i, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;
     rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I,
-                         (int)L.I, nullptr, full, st);
+                         (int)L.I, nullptr, full, nullptr, st);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gcn)
       return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,

@@ -124,8 +124,10 @@ int pgemm_tn_tiles(int Mout, int Nout);   // output tiles per K chunk (sizes the
 size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk);
 int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
                            float* bias_out, const float* scales, hipStream_t st);
+// kpart (nullable): pgemm_nt_kpart_floats(M, ldc, Kp) floats of split-K scratch for few-row, long-K products
+size_t pgemm_nt_kpart_floats(int M, int ldc, int Kp);
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                    int ldc, int N, const float* s_out, bool x3, hipStream_t st);
+                    int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st);
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
                     int K, int splitk, float* partial, int Mout, int Nout, bool x3, hipStream_t st);
 // general shapes (general.hip): CSR adjacency (blob layout: see include/windgnn.h) and any hidden width
@@ -138,10 +140,11 @@ int launch_gcn2_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float
                         const float* scales, float* du, float* partial, float* dW1, float* db1, float* dW2, float* db2,
                         hipStream_t st);
 int launch_gru_gen_fwd_x3(int B, int T, int H, const float* GI, int ldgi, const void* whh_planes, int np_g3,
-                          const float* bhh, float* Y, float* gates, void* y_planes, float* gh, bool x3, hipStream_t st);
+                          const float* bhh, float* Y, float* gates, void* y_planes, float* gh, float* kpart, void* hc,
+                          bool x3, hipStream_t st);
 int launch_gru_gen_bwd_x3(int B, int T, int H, const void* whhT_planes, int np_h, const float* Y, const float* dY,
                           const float* gates, const float* scales, void* dgi_planes, void* dgh_planes, int ldd,
-                          float* dhz, float* dhw, bool x3, hipStream_t st);
+                          float* dhz, float* dhw, float* kpart, void* dc, bool x3, hipStream_t st);
 int launch_gru_gen_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
                        float* gates, float* gh, hipStream_t st);
 int launch_gru_gen_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,

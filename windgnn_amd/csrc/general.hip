@@ -216,7 +216,8 @@ __global__ void gru_cell_bwd_kernel(int B, int T, int t, int H, const float* __r
 __global__ void gru_cell_fwd_x3_kernel(int B, int T, int t, int H, int Hp, const float* __restrict__ GI, int ldgi,
                                        const float* __restrict__ GH, int ldgh, const float* __restrict__ bhh,
                                        float* __restrict__ Y, float* __restrict__ gates, _Float16* __restrict__ yhi,
-                                       _Float16* __restrict__ ylo) {
+                                       _Float16* __restrict__ ylo, _Float16* __restrict__ chi,
+                                       _Float16* __restrict__ clo) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)B * Hp) return;
   const int b = (int)(i / Hp), j = (int)(i % Hp);
@@ -226,8 +227,8 @@ __global__ void gru_cell_fwd_x3_kernel(int B, int T, int t, int H, int Hp, const
     if (ylo) ylo[(size_t)B * T * Hp + j] = (_Float16)0.f;
   }
   if (j >= H) {                    // ones column (-> b_hh / db_hh in the GEMMs) and zero padding
-    yhi[bt * Hp + j] = (_Float16)(j == H ? 1.f : 0.f);
-    if (ylo) ylo[bt * Hp + j] = (_Float16)0.f;
+    yhi[bt * Hp + j] = chi[i] = (_Float16)(j == H ? 1.f : 0.f);
+    if (ylo) ylo[bt * Hp + j] = clo[i] = (_Float16)0.f;
     return;
   }
   const float* gi = GI + bt * ldgi;
@@ -245,8 +246,8 @@ __global__ void gru_cell_fwd_x3_kernel(int B, int T, int t, int H, int Hp, const
   const float h = (1.f - z) * n + z * hprev;
   Y[bt * H + j] = h;
   const _Float16 hh = (_Float16)h;
-  yhi[bt * Hp + j] = hh;
-  if (ylo) ylo[bt * Hp + j] = (_Float16)(h - (float)hh);
+  yhi[bt * Hp + j] = chi[i] = hh;       // c*: the same row in a compact [B][Hp] image, the next step's GEMM operand
+  if (ylo) ylo[bt * Hp + j] = clo[i] = (_Float16)(h - (float)hh);
   if (gates) {
     float* gp = gates + bt * 4 * H;
     gp[j] = r; gp[H + j] = z; gp[2 * H + j] = n; gp[3 * H + j] = ghn;
@@ -265,7 +266,8 @@ __global__ void gru_cell_bwd_x3_kernel(int B, int T, int t, int H, const float* 
                                        const float* __restrict__ scales, float* __restrict__ dhz,
                                        const float* __restrict__ dhw, _Float16* __restrict__ gihi,
                                        _Float16* __restrict__ gilo, _Float16* __restrict__ ghhi,
-                                       _Float16* __restrict__ ghlo, int ldd) {
+                                       _Float16* __restrict__ ghlo, int ldd, _Float16* __restrict__ chi,
+                                       _Float16* __restrict__ clo) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)B * H) return;
   const int b = (int)(i / H), j = (int)(i % H);
@@ -288,9 +290,14 @@ __global__ void gru_cell_bwd_x3_kernel(int B, int T, int t, int H, const float* 
   put_planes(ghhi, ghlo, row + j, dar);
   put_planes(ghhi, ghlo, row + H + j, daz);
   put_planes(ghhi, ghlo, row + 2 * H + j, dnt * r);
+  const size_t crow = (size_t)b * ldd;         // compact [B][ldd] image of this step's dgh: the GEMM operand
+  put_planes(chi, clo, crow + j, dar);
+  put_planes(chi, clo, crow + H + j, daz);
+  put_planes(chi, clo, crow + 2 * H + j, dnt * r);
   for (int c = 3 * H + j; c < ldd; c += H) {   // K padding of the plane rows
     put_planes(gihi, gilo, row + c, 0.f);
     put_planes(ghhi, ghlo, row + c, 0.f);
+    put_planes(chi, clo, crow + c, 0.f);
   }
   dhz[i] = dh * z;
 }
@@ -402,21 +409,24 @@ int launch_gru_gen_bwd(int B, int T, int H, const float* Whh, const float* Y, co
 // whh_planes: split(W_hh | b_hh) as launch_split_weight2(w_hh, 3H, H, 0, b_hh, H, ., pgemm_nt_np(3H), Hp) makes it;
 // y_planes: 2 x [B*T+1][Hp] halfs (hi, lo); gh: [B][ldgi] floats.
 int launch_gru_gen_fwd_x3(int B, int T, int H, const float* GI, int ldgi, const void* whh_planes, int np_g3,
-                          const float* bhh, float* Y, float* gates, void* y_planes, float* gh, bool x3,
-                          hipStream_t st) {
+                          const float* bhh, float* Y, float* gates, void* y_planes, float* gh, float* kpart,
+                          void* hc /*B*Hp floats*/, bool x3, hipStream_t st) {
   const int Hp = grux_hp(H);
   _Float16* yhi = (_Float16*)y_planes;
   _Float16* ylo = yhi + ((size_t)B * T + 1) * Hp;
+  // The GEMM reads h_{t-1} from a compact [B][Hp] copy: rows of the [B*T][Hp] planes are T*Hp apart, and 64-byte
+  // row segments that far apart (0.6 MB at H = 12288) cost 5x in the staging loads.
+  _Float16* chi = (_Float16*)hc;
+  _Float16* clo = chi + (size_t)B * Hp;
   const int nb = (int)(((long long)B * Hp + 255) / 256);
   for (int t = 0; t < T; ++t) {
     if (t > 0) {   // gh = [h_{t-1} | 1] (W_hh | b_hh)^T
-      int rc = launch_pgemm_nt(yhi + (size_t)(t - 1) * Hp, ylo + (size_t)(t - 1) * Hp, T * Hp, B, Hp, whh_planes, np_g3,
-                               gh, ldgi, 3 * H, nullptr, x3, st);
+      int rc = launch_pgemm_nt(chi, clo, Hp, B, Hp, whh_planes, np_g3, gh, ldgi, 3 * H, nullptr, x3, kpart, st);
       if (rc != WGNN_OK) return rc;
     }
     PROF_LAUNCH("gru_cell_fwd_x3_kernel", 0.0, (double)B * H * 4.0 * 10, st,
                 hipLaunchKernelGGL(gru_cell_fwd_x3_kernel, dim3(nb), dim3(256), 0, st, B, T, t, H, Hp, GI, ldgi, gh, ldgi,
-                                   bhh, Y, gates, yhi, x3 ? ylo : (_Float16*)nullptr));
+                                   bhh, Y, gates, yhi, x3 ? ylo : (_Float16*)nullptr, chi, clo));
     WGNN_CHECK_LAUNCH();
   }
   return WGNN_OK;
@@ -426,8 +436,10 @@ int launch_gru_gen_fwd_x3(int B, int T, int H, const float* GI, int ldgi, const 
 // dgi / dgh planes: hi [B*T][ldd] followed by lo [B*T][ldd]
 int launch_gru_gen_bwd_x3(int B, int T, int H, const void* whhT_planes, int np_h, const float* Y, const float* dY,
                           const float* gates, const float* scales, void* dgi_planes, void* dgh_planes, int ldd,
-                          float* dhz, float* dhw, bool x3, hipStream_t st) {
+                          float* dhz, float* dhw, float* kpart, void* dc /*B*ldd floats*/, bool x3, hipStream_t st) {
   const size_t PG = (size_t)B * T * ldd;
+  _Float16* chi = (_Float16*)dc;               // compact [B][ldd] planes of the current step's dgh
+  _Float16* clo = chi + (size_t)B * ldd;
   _Float16* gihi = (_Float16*)dgi_planes;
   _Float16* ghhi = (_Float16*)dgh_planes;
   _Float16* gilo = x3 ? gihi + PG : nullptr;
@@ -436,11 +448,10 @@ int launch_gru_gen_bwd_x3(int B, int T, int H, const void* whhT_planes, int np_h
   for (int t = T - 1; t >= 0; --t) {
     PROF_LAUNCH("gru_cell_bwd_x3_kernel", 0.0, (double)B * H * 4.0 * 14, st,
                 hipLaunchKernelGGL(gru_cell_bwd_x3_kernel, dim3(nb), dim3(256), 0, st, B, T, t, H, Y, dY, gates, scales,
-                                   dhz, dhw, gihi, gilo, ghhi, ghlo, ldd));
+                                   dhz, dhw, gihi, gilo, ghhi, ghlo, ldd, chi, x3 ? clo : (_Float16*)nullptr));
     WGNN_CHECK_LAUNCH();
     if (t > 0) {   // dhw = dGH_t W_hh, stays in scaled units
-      int rc = launch_pgemm_nt(ghhi + (size_t)t * ldd, ghhi + PG + (size_t)t * ldd, T * ldd, B, ldd, whhT_planes, np_h,
-                               dhw, H, H, nullptr, x3, st);
+      int rc = launch_pgemm_nt(chi, clo, ldd, B, ldd, whhT_planes, np_h, dhw, H, H, nullptr, x3, kpart, st);
       if (rc != WGNN_OK) return rc;
     }
   }

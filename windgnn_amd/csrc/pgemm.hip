@@ -45,7 +45,18 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
                                                                 int Kp, const _Float16* __restrict__ Bpl, int Np,
                                                                 float* __restrict__ C, int ldc, int N,
                                                                 const float* __restrict__ s_out_p, int nm, int nsl,
-                                                                size_t bplane, int accumulate) {
+                                                                size_t bplane, int kc_len, int kc_first,
+                                                                size_t cstride, int accumulate) {
+  // K chunking (long contractions): this block multiplies columns [k0, k0 + Kp) of the operands, chunk index
+  // kc_first + blockIdx.y, into C + blockIdx.y * cstride (split-K partials) or straight into / onto C.
+  {
+    const int k0 = (kc_first + (int)blockIdx.y) * kc_len;
+    Ahi += k0;
+    Alo += k0;
+    Bpl += (size_t)(k0 / 32) * Np * 32;
+    C += (size_t)blockIdx.y * cstride;
+    Kp = min(kc_len, Kp - k0);
+  }
   constexpr int BM = NT_BM, BNW = 16 * T, BN = 2 * BNW;
   constexpr int A_PL = BM * 64, B_PL = BN * 64, STAGE = 2 * A_PL + 2 * B_PL;
   constexpr int PL = X3 ? 2 : 1;                                   // planes moved: hi (+ lo)
@@ -57,8 +68,16 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
   const int wm = wave % 6, wn = wave / 6;
   // blocks {b, b+8, ...} (same XCD, dispatched together) are the N slices of one M tile: the A tile is
   // fetched from HBM once and re-read from that XCD's L2 by the sibling slices.
-  const int grp = blockIdx.x / (8 * nsl), within = blockIdx.x % (8 * nsl);
-  const int sl = within / 8, mt = grp * 8 + within % 8;
+  // (With fewer than 8 M tiles that padding would leave whole XCDs without work: plain order then.)
+  int sl, mt;
+  if (nm >= 8) {
+    const int grp = blockIdx.x / (8 * nsl), within = blockIdx.x % (8 * nsl);
+    sl = within / 8;
+    mt = grp * 8 + within % 8;
+  } else {
+    sl = blockIdx.x / nm;
+    mt = blockIdx.x % nm;
+  }
   if (mt >= nm) return;
   const int m0 = mt * BM, n0 = sl * BN;
   const float s_out = s_out_p ? s_out_p[1] : 1.f;
@@ -411,48 +430,78 @@ int launch_split_weight2(const float* W, int R, int C, int transpose, const floa
   return WGNN_OK;
 }
 
+// C = sum over chunks of the split-K partials [nchunks][n] (fixed order), float4 per thread
+__global__ void nt_ksum_kernel(const float* __restrict__ part, int nchunks, size_t n4, float* __restrict__ C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = ((const f32x4*)part)[i];
+  for (int c = 1; c < nchunks; ++c) s += ((const f32x4*)part)[(size_t)c * n4 + i];
+  ((f32x4*)C)[i] = s;
+}
+
 // NT tiling of N: nsl slices of 32T columns (T <= 14: two stages of (192 + 448) 128-byte rows are exactly the
-// CU's 160 KB of LDS), as few slices as possible and as narrow as they can be.
-static void nt_shape(int N, int& nsl, int& T) {
+// CU's 160 KB of LDS), as few slices as possible and as narrow as they can be -- unless that leaves most CUs
+// without a workgroup (few rows: the per-step GEMMs of a wide GRU, small batches), in which case N is cut finer.
+constexpr int NT_KC = 2048;   // K chunk of long contractions: <= 64 chained MFMA steps per fp32 accumulator
+static int nt_chunks(int Kp) { return Kp > NT_KC + NT_KC / 2 ? cdiv_i(Kp, NT_KC) : 1; }
+static void nt_shape(int M, int N, int Kp, bool splitk, int& nsl, int& T) {
   nsl = cdiv_i(N, 448);
   T = cdiv_i(cdiv_i(N, nsl), 32);
+  const int nm = cdiv_i(M, NT_BM);
+  if (nm * nsl * (splitk ? nt_chunks(Kp) : 1) < 192) {
+    int want = cdiv_i(256, nm);                       // slices that would give every CU a workgroup
+    if (want > cdiv_i(N, 32)) want = cdiv_i(N, 32);
+    T = cdiv_i(cdiv_i(N, want), 32);
+    nsl = cdiv_i(N, 32 * T);
+  }
 }
-int pgemm_nt_np(int N) {
-  int nsl, T;
-  nt_shape(N, nsl, T);
-  return nsl * 32 * T;
-}
+// floats of split-K scratch that make a few-row, long-K product (the per-step GEMMs of a wide GRU) fill the chip
+size_t pgemm_nt_kpart_floats(int M, int ldc, int Kp) { return nt_chunks(Kp) > 1 ? (size_t)nt_chunks(Kp) * M * ldc : 0; }
+// rows of the B planes: any tiling nt_shape can pick stays inside them (rows >= N are zero)
+int pgemm_nt_np(int N) { return cdiv_i(N, 32) * 32 + 448 - 32; }
 
 template <int T>
 static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                       int ldc, int N, const float* s_out, bool x3, int nsl, hipStream_t st) {
+                       int ldc, int N, const float* s_out, bool x3, int nsl, float* kpart, hipStream_t st) {
   const int nm = cdiv_i(M, NT_BM);
-  const int grid = cdiv_i(nm, 8) * 8 * nsl;
+  const int grid = (nm >= 8 ? cdiv_i(nm, 8) * 8 : nm) * nsl;
   const size_t smem = 2 * (size_t)(2 * NT_BM + 2 * 32 * T) * 64;
   static std::atomic<unsigned long long> done{0}, done16{0};
   if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
   if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
   static const std::string name = "pgemm_nt_kernel<" + std::to_string(T) + ">", name16 = "pgemm_nt_kernel<" + std::to_string(T) + ",f16>";
-  // Long contractions (the 4096-station projections: K = 53 248) run as 2048-wide K chunks accumulated in C:
-  // an fp32 accumulator chain of at most 64 MFMA steps per chunk keeps the summation error at fp32-GEMM level.
-  constexpr int KC = 2048;
-  const int nchunks = Kp > KC + KC / 2 ? cdiv_i(Kp, KC) : 1;
+  // Long contractions (the 4096-station projections: K = 53 248) run as 2048-wide K chunks: an fp32 accumulator
+  // chain of at most 64 MFMA steps per chunk keeps the summation error at fp32-GEMM level.  With split-K scratch
+  // the chunks are blocks of ONE launch (partials summed in fixed order); without, one launch per chunk adds onto C.
+  const int nchunks = nt_chunks(Kp), kc_len = nchunks > 1 ? NT_KC : Kp;
   const size_t bplane = (size_t)Np * Kp;
-  for (int c = 0; c < nchunks; ++c) {
-    const int k0 = nchunks > 1 ? c * KC : 0, kc = nchunks > 1 ? (Kp - k0 < KC ? Kp - k0 : KC) : Kp;
-    const _Float16* ah = (const _Float16*)Ahi + k0;
-    const _Float16* al = (const _Float16*)Alo + k0;
-    const _Float16* bp = (const _Float16*)Bplanes + (size_t)(k0 / 32) * Np * 32;
-    const double fl = 2.0 * M * (double)N * kc;
-    const double by = (x3 ? 4.0 : 2.0) * ((double)M * kc + (double)Np * kc) + 4.0 * (double)M * N * (c > 0 ? 2 : 1);
+  const bool split = kpart && nchunks > 1;
+  const int nlaunch = split ? 1 : nchunks;
+  for (int c = 0; c < nlaunch; ++c) {
+    const dim3 g(grid, split ? nchunks : 1);
+    float* out = split ? kpart : C;
+    const size_t cstride = split ? (size_t)M * ldc : 0;
+    const double kk = split ? Kp : (Kp - c * kc_len < kc_len ? Kp - c * kc_len : kc_len);
+    const double fl = 2.0 * M * (double)N * kk;
+    const double by = (x3 ? 4.0 : 2.0) * ((double)M * kk + (double)Np * kk) + 4.0 * (double)M * N * (split ? nchunks : (c > 0 ? 2 : 1));
     if (x3)
       PROF_LAUNCH(name.c_str(), fl, by, st,
-                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true>), dim3(grid), dim3(64 * NT_WAVES), smem, st, ah, al, lda, M,
-                                     kc, bp, Np, C, ldc, N, s_out, nm, nsl, bplane, c > 0 ? 1 : 0));
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                                     (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
+                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
     else
       PROF_LAUNCH(name16.c_str(), fl, by, st,
-                  hipLaunchKernelGGL((pgemm_nt_kernel<T, false>), dim3(grid), dim3(64 * NT_WAVES), smem, st, ah, al, lda, M,
-                                     kc, bp, Np, C, ldc, N, s_out, nm, nsl, bplane, c > 0 ? 1 : 0));
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                                     (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
+                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
+    WGNN_CHECK_LAUNCH();
+  }
+  if (split) {
+    if (((size_t)M * ldc) % 4 != 0) return WGNN_ERR_SHAPE;
+    const size_t n4 = (size_t)M * ldc / 4;
+    PROF_LAUNCH("nt_ksum_kernel", 0.0, 16.0 * n4 * (nchunks + 1), st,
+                hipLaunchKernelGGL(nt_ksum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, kpart, nchunks, n4,
+                                   C));
     WGNN_CHECK_LAUNCH();
   }
   return WGNN_OK;
@@ -460,13 +509,13 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
 
 // C[M][N] = s_out * A B^T.  A planes [M][lda] (Kp <= lda), B stage-major planes with Np = pgemm_nt_np(N) rows.
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                    int ldc, int N, const float* s_out, bool x3, hipStream_t st) {
+                    int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st) {
   int nsl, T;
-  nt_shape(N, nsl, T);
-  if (Kp % 32 != 0 || lda % 8 != 0 || Np != nsl * 32 * T) return WGNN_ERR_SHAPE;
+  nt_shape(M, N, Kp, kpart != nullptr, nsl, T);
+  if (Kp % 32 != 0 || lda % 8 != 0 || Np < nsl * 32 * T) return WGNN_ERR_SHAPE;
   switch (T) {
 #define NT_CASE(t) \
-  case t: return launch_nt_t<t>(Ahi, Alo, lda, M, Kp, Bplanes, Np, C, ldc, N, s_out, x3, nsl, st);
+  case t: return launch_nt_t<t>(Ahi, Alo, lda, M, Kp, Bplanes, Np, C, ldc, N, s_out, x3, nsl, kpart, st);
     NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5) NT_CASE(6) NT_CASE(7) NT_CASE(8) NT_CASE(9) NT_CASE(10)
     NT_CASE(11) NT_CASE(12) NT_CASE(13) NT_CASE(14)
 #undef NT_CASE
