@@ -175,7 +175,7 @@ def main():
         t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
         t_mfma = d["flops"] / (eff_peak * 1e12)
         bound = "hbm" if (d["name"].startswith(BOUND_HBM_PREFIXES) or t_hbm >= t_mfma) else "mfma"
-        tr = measured_traffic(d["name"])
+        tr = measured_traffic(d["name"]) if args.workload == "c3" else None   # the PMC passes are of the c3 workload
         if bound == "mfma":
             ach = d["flops"] / d["launches"] / avg_s / 1e12
             peak = MFMA_PEAK_TFLOPS[args.math]
