@@ -321,14 +321,18 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 // Backward of both layers for one tile (no dX: the input does not require grad).  With
 //   U1 = X W1, H1 = relu(A U1 + b1)      (recomputed),  dZ2 = dg * (g > 0) * scale
 //   dU2 = A^T dZ2                 dW2 += H1^T dU2        db2 += colsum(dZ2)
-//   dU2t = dZ2^T A  (= dU2^T)     dH1 = dU2 W2^T         dZ1 = dH1 * (H1 > 0)
+//                                 dH1 = dU2 W2^T         dZ1 = dH1 * (H1 > 0)
 //   dU1 = A^T dZ1                 dW1 += X^T dU1         db1 += colsum(dZ1)
 // every product contracts over the row index of an accumulator stack (or of a tile staged in LDS and
-// read in C layout).  A and A^T fragments live in LDS (shared by the 4 waves); dg is scaled by the
+// read in C layout).  A and A^T fragments live in LDS (shared by the block's waves); dg is scaled by the
 // power of two scales[0] so fp16 never sees ~1e-9 values and the partial sums are un-scaled by
 // scales[1] at the end.
+// 12 waves per backward block, one block per CU: the chain of small dependent products is latency-bound, and
+// three waves per SIMD (166 VGPRs) hide more of it than two (measured 181 vs 198 us; 4-wave blocks, 2 per CU).
+constexpr int BWD_WAVES = 12;
+
 template <int NT, bool X3>
-__global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
+__global__ void __launch_bounds__(64 * BWD_WAVES) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const _Float16* __restrict__ gact, int ld_g,
@@ -340,8 +344,8 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
   __shared__ __attribute__((aligned(16))) h8 sCA[2 * NF * 64];   // [frag][hi|lo][lane]
   __shared__ __attribute__((aligned(16))) h8 sCT[2 * NF * 64];
-  __shared__ __attribute__((aligned(16))) float sbuf[4 * 2 * SP * XS];
-  __shared__ float red[4 * PART];
+  __shared__ __attribute__((aligned(16))) float sbuf[BWD_WAVES * 2 * SP * XS];
+  static_assert(2 * SP * XS >= PART, "the per-wave staging buffer doubles as its reduction row");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int I = S * F13;
   float* xb = sbuf + wave * 2 * SP * XS;
@@ -389,8 +393,7 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
     for (int j = 0; j < 8; ++j) {
       const int f = 8 * g + j;
       x1[j] = (f < F13 && c < F13) ? W1[f * F13 + c] : 0.f;
-      const int fp = 4 * g + j;                      // k = f' (rho order, one tile), n = c = f: W2^T[f'][f]
-      x2[j] = (j < 4 && fp < F13 && c < F13) ? W2[c * F13 + fp] : 0.f;
+      x2[j] = (f < F13 && c < F13) ? W2[c * F13 + f] : 0.f;   // k = f' natural, n = c = f: W2^T[f'][f]
     }
     FW1 = split_vals<X3>(x1);
     FW2T = split_vals<X3>(x2);
@@ -480,13 +483,18 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
       const f32x4 d1 = (2 * ks + 1 < NT) ? dU[2 * ks + 1] : zero4;
       dW2acc = mfma3<X3>(frag_of<X3>(H1[2 * ks], h1), frag_of<X3>(dU[2 * ks], d1), dW2acc);
     }
-    // ---- dU2t [f'][s'] = dZ2^T A ; dH1 [s'][f] = dU2 W2^T ; dZ1 = dH1 * (H1 > 0)
+    // ---- dH1 [s'][f] = dU2 W2^T contracts over dU2's COLUMN index: dU2 goes through the wave's staging buffer
+    // (the dZ2 tile in it has been consumed) and comes back as natural-k A fragments -- 12 ds_write_b32 + 6
+    // ds_read_b128 per lane instead of the 18 MFMAs of a second, transposed A product.  dZ1 = dH1 * (H1 > 0).
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) db[(16 * i + 4 * g + r) * XS + c] = dU[i][r];
+    wave_lds_fence();
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      f32x4 acc = zero4;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(DZF[ks], ldT(n, ks), acc);
-      const f32x4 dh = mfma3<X3>(frag_of<X3>(acc, zero4), FW2T, zero4);
+      const f32x4 dh = mfma3<X3>(xfrag_nat<X3>(db, n, c, g), FW2T, zero4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = H1[n][r] > 0.f ? dh[r] : 0.f;
@@ -518,6 +526,8 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
   }
 
   // ---- per-block reduction of the 4 waves, one partial row per block (deterministic order)
+  float* red = sbuf;                 // staging is over: reuse it, one PART row per wave
+  __syncthreads();
   float* mine = red + wave * PART;
   for (int i = lane; i < PART; i += 64) mine[i] = 0.f;
   __syncthreads();
@@ -537,12 +547,18 @@ __global__ void __launch_bounds__(256) gcnx_bwd_kernel(int ntiles, int S, const 
   }
   __syncthreads();
   for (int i = threadIdx.x; i < PART; i += blockDim.x)
-    partial[(size_t)blockIdx.x * PART + i] = red[i] + red[PART + i] + red[2 * PART + i] + red[3 * PART + i];
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < BWD_WAVES; ++w) t += red[w * PART + i];   // fixed order
+    partial[(size_t)blockIdx.x * PART + i] = t;
+  }
 }
 
 int grid_x(int ntiles) {
-  int g = cdiv_i(ntiles, 4);
-  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+  int g = cdiv_i(ntiles, BWD_WAVES);
+  const int cap = 256;                              // one block per CU, persistent over the tiles
+  return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
 }  // namespace
@@ -590,11 +606,11 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const fl
 #define BWD_CASE(NT)                                                                                               \
   if (x3)                                                                                                          \
     PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                            \
-                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, g,  \
+                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(64 * BWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, g,  \
                                    ldg, dg, scales, scale_in, partial));                                           \
   else                                                                                                             \
     PROF_LAUNCH("gcnx_bwd_kernel<" #NT ",f16>", fl, by, st,                                                        \
-                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(256), 0, st, ntiles, S, A, X, W1, b1, W2, g, \
+                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(64 * BWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, g, \
                                    ldg, dg, scales, scale_in, partial))
   switch ((S + 15) / 16) {
     case 1: BWD_CASE(1); break;
