@@ -52,7 +52,6 @@ __global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, 
   const bool jv = active && j < H;
   const int jc = jv ? j : H - 1;
   const int b0 = blockIdx.x * MB;
-  const int G3 = 3 * H;
   const float bh_r = bhh[jc], bh_z = bhh[H + jc], bh_n = bhh[2 * H + jc];
 
   float gi[3][4];
