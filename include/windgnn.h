@@ -131,6 +131,16 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
                   const float* Y, const float* dY, const void* stash, const wgnn_grads* g,
                   void* workspace, size_t workspace_bytes, void* stream, int part /* bit mask 1..7 */);
 
+/* The reference's loss call folded into the backward (src/main.py:72 + :79): gradients of
+ * grad_scale * mean((Y - labels)^2) w.r.t. the 8 parameters, and loss[0] = mean((Y - labels)^2) (written by the call
+ * that has part bit 1).  Same parts, scratch and ordering as wgnn_bwd_part; equal to wgnn_mse_loss_grad followed by
+ * wgnn_bwd_part, but dY [B,T,H] is not written or re-read where the recurrence kernel can form it from Y and the
+ * labels (f16x3 / f16, H <= 127); other shapes build dY inside the workspace. */
+int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p,
+                      const float* Y, const float* labels /* [B,T,H] */, float grad_scale, float* loss,
+                      const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
+                      void* stream, int part /* bit mask 1..7 */);
+
 /* One GraphConvLayer: out[n,S,F] = relu(A X[n] W + b) for n = 0..ntiles-1 (ntiles = prod of the
  * leading dims of attr_matrix).  Backward: dW, db (overwritten) and, if dX != NULL, dX. */
 size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F);

@@ -401,3 +401,37 @@ def test_4096_station_csr_config_full_width_stations(math):
     assert max_abs(out.reshape(Yo.shape), Yo) <= Y_TOL
     for key in PARAM_KEYS:
         assert rel_to_max(grads[key], go[key]) <= G_TOL, key
+
+
+@pytest.mark.parametrize("S,T,B,H,math", [(34, 24, 37, 102, "f16x3"), (34, 24, 37, 102, "f16"), (7, 12, 5, 21, "f16x3"),
+                                          (34, 6, 9, 102, "f32"), (20, 4, 6, 200, "f16x3"), (1, 1, 1, 1, "f16x3")])
+def test_fused_loss_backward_equals_loss_then_backward(S, T, B, H, math):
+    """wgnn_bwd_mse_part (what TrainStep calls) against wgnn_mse_loss_grad + wgnn_bwd and against the oracle, for
+    the kernel that forms dY from the labels itself (f16x3 / f16, H <= 127) and for the shapes that build dY."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.functional import gcn_gru_backward_mse_raw, gcn_gru_forward_raw
+    dev = _dev()
+    g = torch.Generator().manual_seed(31 + S + H)
+    A = torch.rand(S, S, generator=g) / S + 0.01
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    p = orc.init_params(S, 13, H, seed=S)
+    Yo, loss_o, go = _oracle_step(A, X, L, p)
+    model = _model_from(p, S, H, math)
+    out, loss_u, grads_u = _run_step(model, A.to(dev), X.to(dev), L.to(dev))          # loss op, then backward
+    params = [q.detach() for q in model.hot_path_parameters()]
+    Y, stash, d = gcn_gru_forward_raw(A.to(dev), X.to(dev), params, model.math, want_stash=True)
+    grads = [torch.empty_like(q) for q in params]
+    loss = torch.empty((), device=dev)
+    gcn_gru_backward_mse_raw(d, A.to(dev), X.to(dev), params, Y, L.to(dev), stash, grads, loss, 1.0)
+    tol = 5e-2 if math == "f16" else G_TOL
+    assert abs(float(loss) - float(loss_o)) <= (2e-3 if math == "f16" else 1e-5) * max(1.0, float(loss_o))
+    for key, gf in zip(PARAM_KEYS, grads):
+        assert rel_to_max(gf.cpu(), go[key]) <= tol, key
+        assert rel_to_max(gf.cpu(), grads_u[key]) <= (1e-3 if math == "f16" else 2e-5), key
+    # in two parts, with a gradient scale (the data-parallel call pattern)
+    grads2 = [torch.empty_like(q) for q in params]
+    gcn_gru_backward_mse_raw(d, A.to(dev), X.to(dev), params, Y, L.to(dev), stash, grads2, loss, 0.5, part=1 | 4)
+    gcn_gru_backward_mse_raw(d, A.to(dev), X.to(dev), params, Y, L.to(dev), stash, grads2, loss, 0.5, part=2)
+    for a, b in zip(grads, grads2):
+        assert rel_to_max(2.0 * b.cpu(), a.cpu()) <= 1e-6

@@ -42,6 +42,9 @@ EXPORTS = {
                            C.c_void_p, C.POINTER(Grads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "wgnn_bwd_part": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.POINTER(Grads), C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    "wgnn_bwd_mse_part": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
+                                    C.c_float, C.c_void_p, C.c_void_p, C.POINTER(Grads), C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_int]),
     "wgnn_gcn_layer_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "wgnn_gcn_layer_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

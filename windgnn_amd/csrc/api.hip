@@ -15,7 +15,7 @@ struct Layout {
   // stash
   size_t st_g, st_gates, st_yp, stash_floats;
   // backward workspace
-  size_t ws_dGI, ws_dGH, ws_dg, ws_part, ws_gcnpart, ws_planes_b, ws_scales, bwd_floats;
+  size_t ws_dGI, ws_dGH, ws_dg, ws_part, ws_gcnpart, ws_planes_b, ws_scales, ws_dY, bwd_floats;
   int sk_ih, sk_hh;
   // which kernels run: the fp16-plane family needs the dense LDS-resident GCN and the register-resident GRU;
   // shapes beyond the fast kernels (CSR adjacency, wide hidden state) use general.hip in exact fp32
@@ -99,7 +99,8 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_kp_b = o; o += al(L.gen_gru && x3 ? pgemm_nt_kpart_floats(d->B, (int)L.H, (int)L.Gp) : 0);
   L.ws_dc = o; o += al(L.gen_gru && x3 ? (size_t)d->B * L.Gp : 0);          // compact planes of dgh_t
   L.ws_planes_b = o; o += al(planes_b);
-  L.ws_scales = o; o += al(512);
+  L.ws_scales = o; o += al(4096);          // 3 scales, then up to 2 x 1024 block partials from offset 64
+  L.ws_dY = o; o += al(L.BT * L.H);          // wgnn_bwd_mse_part outside the fused kernel: dY lives here
   L.bwd_floats = o;
   return L;
 }
@@ -228,14 +229,20 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   return wgnn_bwd_part(d, A, X, p, Y, dY, stash, g, workspace, workspace_bytes, stream, 7);
 }
 
-int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
-                  const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
-                  void* stream, int which) {
+}  // extern "C"
+
+namespace {
+// The backward behind wgnn_bwd_part (dY given) and wgnn_bwd_mse_part (labels given: dY = 2 (Y - labels) grad_scale / n
+// is never written when the register-resident f16x3 recurrence runs; loss[0] = mean((Y - labels)^2)).
+int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
+             const float* dY, const float* labels, float grad_scale, float* loss, const void* stash,
+             const wgnn_grads* g, void* workspace, size_t workspace_bytes, void* stream, int which) {
   if (which < 1 || which > 7) return WGNN_ERR_SHAPE;
   const bool do_rec = which & 1, do_gcn = which & 2, do_wg = which & 4;
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
-  if (!A || !X || !p || !Y || !dY || !stash || !g || !workspace) return WGNN_ERR_NULL;
+  if (!A || !X || !p || !Y || (!dY && !labels) || !stash || !g || !workspace) return WGNN_ERR_NULL;
+  if (labels && do_rec && !loss) return WGNN_ERR_NULL;
   if (!g->conv1_weight || !g->conv1_bias || !g->conv2_weight || !g->conv2_bias || !g->w_ih || !g->w_hh ||
       !g->b_ih || !g->b_hh)
     return WGNN_ERR_NULL;
@@ -250,9 +257,15 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
   float* dGH = ws + L.ws_dGH;
   float* dg = ws + L.ws_dg;
   float* part = ws + L.ws_part;
-  float* scales = ws + L.ws_scales;          // [0] = 2^k, [1] = 2^-k (f16x3 range scaling), then 256 partials
+  float* scales = ws + L.ws_scales;          // [0] = 2^k, [1] = 2^-k (f16x3 range scaling), [2] = dY coefficient; partials from 64
   const bool x3 = L.x3;
   const bool full = d->math == WGNN_MATH_F16X3;
+  const bool fused_loss = labels && x3 && !L.gen_gru;      // the recurrence kernel forms dY from the labels itself
+  if (labels && !fused_loss && do_rec) {                   // other kernels: materialise dY in the workspace
+    rc = launch_mse(Y, labels, (int64_t)L.BT * L.H, grad_scale, ws + L.ws_dY, loss, scales + 64, st);
+    if (rc != WGNN_OK) return rc;
+  }
+  if (labels && !fused_loss) dY = ws + L.ws_dY;
 
   if (x3) {
     // Everything downstream of dY is linear in it: run it in units scaled by scales[0] = 2^k (so that
@@ -263,7 +276,10 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
     const _Float16* yph = (const _Float16*)(sf + L.st_yp);
     const size_t PG = L.BT * L.Gp;
     if (do_rec) {
-      rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the 2 scales
+      if (fused_loss)   // loss, the range scale and the dY coefficient in one pass over Y and the labels
+        rc = launch_mse_stats(Y, labels, (int64_t)L.BT * L.H, grad_scale, loss, scales, scales + 64, st);
+      else
+        rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the scales
       if (rc != WGNN_OK) return rc;
       if (L.gen_gru) {
         rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 1, nullptr, 0, ws + L.ws_hhp_b, L.np_h, (int)L.Gp, st);
@@ -271,7 +287,8 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
         rc = launch_gru_gen_bwd_x3(d->B, d->T, d->H, ws + L.ws_hhp_b, L.np_h, Y, dY, gates, scales, dGIh, dGHh,
                                    (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, ws + L.ws_kp_b, ws + L.ws_dc, full, st);
       } else {
-        rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
+        rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, fused_loss ? nullptr : dY, fused_loss ? labels : nullptr,
+                             gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
       }
       if (rc != WGNN_OK) return rc;
     }
@@ -355,6 +372,24 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
                                g->conv2_weight, g->conv2_bias, st);
   return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                          g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);
+}
+}  // namespace
+
+extern "C" {
+
+int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
+                  const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
+                  void* stream, int which) {
+  if (!dY) return WGNN_ERR_NULL;
+  return bwd_impl(d, A, X, p, Y, dY, nullptr, 1.f, nullptr, stash, g, workspace, workspace_bytes, stream, which);
+}
+
+int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
+                      const float* labels, float grad_scale, float* loss, const void* stash, const wgnn_grads* g,
+                      void* workspace, size_t workspace_bytes, void* stream, int which) {
+  if (!labels) return WGNN_ERR_NULL;
+  return bwd_impl(d, A, X, p, Y, nullptr, labels, grad_scale, loss, stash, g, workspace, workspace_bytes, stream,
+                  which);
 }
 
 size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F) {

@@ -89,13 +89,17 @@ int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* 
                          int ncols_main, float* bias_out, const float* scales /*nullable: *= scales[1]*/,
                          hipStream_t st);
 
+int launch_mse_stats(const float* Y, const float* L, int64_t n, float grad_scale, float* loss, float* scales,
+                     float* part /*>= 2048 floats*/, hipStream_t st);
 int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>= 448 floats*/, hipStream_t st);
 // split-fp16 GRU recurrences with register-resident weights (grux.hip)
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
                     float* gates, void* y_planes, bool x3, hipStream_t st);
-int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
+// exactly one of dY / labels is non-null (labels: dY = (Y - labels) * scales[2], see launch_mse_stats)
+int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
+                    const float* gates,
                     const float* scales, void* dGI_planes, void* dGH_planes, int ldd, bool x3, hipStream_t st);
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,

@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
 template <int KS3, bool X3>   // K steps of 32 over the 3H gate rows
 __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
                                                             const float* __restrict__ Y, const float* __restrict__ dY,
+                                                            const float* __restrict__ Lab,
                                                             const float* __restrict__ gates,
                                                             const float* __restrict__ scales,
                                                             _Float16* __restrict__ dGI_hi, _Float16* __restrict__ dGI_lo,
@@ -237,6 +238,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   const int b0 = blockIdx.x * MB;
   const int G3 = 3 * H;
   const float s_in = scales ? scales[0] : 1.f;
+  // fused MSE (wgnn_bwd_mse_part): dY is not materialised, dY[b,t] = (Y[b,t] - L[b,t]) * scales[2] is formed here;
+  // Y[b,t] is the h_prev this kernel loaded for step t+1, so only L is read in dY's place.
+  const float coef = Lab ? scales[2] : 1.f;
 
   Frag WT[KS3];                                    // B operand: W_hh[k][j], k = 32ks + 8g + jj (gate row)
 #pragma unroll
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     WT[ks] = split_vals(x);
   }
   const float* gatesw = gates + (size_t)b0 * T * 4 * H;     // workgroup-uniform bases + 32-bit lane offsets
-  const float* dYw = dY + (size_t)b0 * T * H;
+  const float* dYw = (Lab ? Lab : dY) + (size_t)b0 * T * H;
   const float* Yw = Y + (size_t)b0 * T * H;
   int rowt[4];
   bool rowok[4];
@@ -278,6 +282,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   };
   StepIn cur, nxt;
   load_step(T - 1, cur);
+  float ycur[4] = {0.f, 0.f, 0.f, 0.f};
+  if (Lab) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ycur[r] = Yw[(rowt[r] + T - 1) * H + jc];
+  }
   f32x4 dhn = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
@@ -293,7 +302,8 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = 4 * g + r;
-        const float dh = rowok[r] ? cur.dy[r] * s_in + dhn[r] : 0.f;
+        const float dyv = Lab ? (ycur[r] - cur.dy[r]) * coef : cur.dy[r];
+        const float dh = rowok[r] ? dyv * s_in + dhn[r] : 0.f;
         const float rg = cur.r[r], zg = cur.z[r], ng = cur.n[r];
         const float dn = dh * (1.f - zg);
         const float dz = dh * (cur.hp[r] - ng);
@@ -343,6 +353,8 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     }
     dhn = acc;
     __syncthreads();   // measured: without it the waves drift apart and the step gets 8 % slower (LDS contention)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ycur[r] = cur.hp[r];   // Y[b, t-1]
     cur = nxt;
   }
 }
@@ -381,7 +393,8 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
   return WGNN_OK;
 }
 
-int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
+int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
+                    const float* gates,
                     const float* scales, void* dGI_planes, void* dGH_planes, int ldd, bool x3, hipStream_t st) {
   _Float16* ih = (_Float16*)dGI_planes;
   _Float16* il = ih + (size_t)B * T * ldd;
@@ -394,12 +407,12 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const
 #define BCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
     PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                             \
-                hipLaunchKernelGGL((grux_bwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, gates, \
-                                   scales, ih, il, hh, hl, ldd));                                                  \
+                hipLaunchKernelGGL((grux_bwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
+                                   gates, scales, ih, il, hh, hl, ldd));                                                  \
   else                                                                                                             \
     PROF_LAUNCH("grux_bwd_kernel<" #K ",f16>", fl, by * 0.75, st,                                                  \
-                hipLaunchKernelGGL((grux_bwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, gates, \
-                                   scales, ih, il, hh, hl, ldd))
+                hipLaunchKernelGGL((grux_bwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
+                                   gates, scales, ih, il, hh, hl, ldd))
   switch (cdiv_i(3 * H, 32)) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;

@@ -98,7 +98,93 @@ __global__ void amax_finalize_kernel(const float* __restrict__ part, int nblk, f
   }
 }
 
+// Fused-loss backward (wgnn_bwd_mse_part): the loss and the range scale of dY = 2 (Y - L) grad_scale / n in ONE
+// pass over Y and L, without writing dY.  part[b] = sum (Y-L)^2, part[nblk + b] = max |Y-L| of block b.
+__global__ void __launch_bounds__(256) mse_stats_kernel(const float* __restrict__ Y, const float* __restrict__ L,
+                                                        int64_t n, float* __restrict__ part) {
+  __shared__ float red[256], redm[256];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = ((((uintptr_t)Y) | ((uintptr_t)L)) & 15) == 0 ? n / 4 : 0;
+  float acc = 0.f, m = 0.f;
+  int64_t i = gid;
+  for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent 16-byte load pairs in flight
+    f32x4 d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = ((const f32x4*)Y)[i + u * stride] - ((const f32x4*)L)[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc += d[u][0] * d[u][0] + d[u][1] * d[u][1] + d[u][2] * d[u][2] + d[u][3] * d[u][3];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(d[u][0]), fabsf(d[u][1]))), fmaxf(fabsf(d[u][2]), fabsf(d[u][3])));
+    }
+  }
+  for (; i < n4; i += stride) {
+    const f32x4 d = ((const f32x4*)Y)[i] - ((const f32x4*)L)[i];
+    acc += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+  }
+  for (int64_t k = 4 * n4 + gid; k < n; k += stride) {
+    const float d = Y[k] - L[k];
+    acc += d * d;
+    m = fmaxf(m, fabsf(d));
+  }
+  red[threadIdx.x] = acc;
+  redm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[threadIdx.x] += red[threadIdx.x + s];
+      redm[threadIdx.x] = fmaxf(redm[threadIdx.x], redm[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = red[0];
+    part[gridDim.x + blockIdx.x] = redm[0];
+  }
+}
+
+// loss = sum / n; scales = {2^k, 2^-k, coef} with coef = 2 grad_scale / n and 2^k * coef * max|Y-L| in [1, 2)
+__global__ void mse_stats_finalize_kernel(const float* __restrict__ part, int nblk, float inv_n, float coef,
+                                          float* __restrict__ loss, float* __restrict__ scales) {
+  float s = 0.f, m = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 64) {
+    s += part[i];
+    m = fmaxf(m, part[nblk + i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    m = fmaxf(m, __shfl_xor(m, o, 64));
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = s * inv_n;
+    m *= fabsf(coef);
+    float sc = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);
+      sc = ldexpf(1.f, 1 - e);
+    }
+    scales[0] = sc;
+    scales[1] = 1.f / sc;
+    scales[2] = coef;
+  }
+}
+
 }  // namespace
+
+// loss and scales {2^k, 2^-k, 2 grad_scale / n} of the fused-loss backward; part: >= 2048 floats
+int launch_mse_stats(const float* Y, const float* L, int64_t n, float grad_scale, float* loss, float* scales,
+                     float* part, hipStream_t st) {
+  PROF_LAUNCH("mse_stats_kernel", 4.0 * n, 8.0 * n, st,
+              hipLaunchKernelGGL(mse_stats_kernel, dim3(MSE_BLOCKS), dim3(256), 0, st, Y, L, n, part));
+  WGNN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mse_stats_finalize_kernel, dim3(1), dim3(64), 0, st, part, MSE_BLOCKS, 1.0f / (float)n,
+                     2.0f * grad_scale / (float)n, loss, scales);
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
 
 int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=448 floats*/, hipStream_t st) {
   PROF_LAUNCH("amax_partial_kernel", (double)n, 4.0 * n, st,

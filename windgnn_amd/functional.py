@@ -98,6 +98,24 @@ def gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, grads: Sequence[torch.Te
     _lib.check(rc, "wgnn_bwd_part(%d)" % part)
 
 
+def gcn_gru_backward_mse_raw(d, A, X, params, Y, L, stash, grads: Sequence[torch.Tensor], loss: torch.Tensor,
+                             grad_scale: float = 1.0, part: int = 7):
+    """wgnn_bwd_mse_part: the backward of grad_scale * mean((Y - L)^2) with the loss call folded in (src/main.py:72,79);
+    `loss` (0-dim device tensor) receives mean((Y - L)^2) from the call that has part bit 1."""
+    lib = _lib.load()
+    _require_gpu(L)
+    if L.numel() != Y.numel():
+        raise RuntimeError("windgnn_amd: MSE operands differ in size: %s vs %s" % (tuple(Y.shape), tuple(L.shape)))
+    A = getattr(A, "blob", A)
+    ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
+    ws = _Workspace.get(X.device, ws_bytes)
+    ps = _params_struct(_lib.Params, params)
+    gs = _params_struct(_lib.Grads, grads)
+    rc = lib.wgnn_bwd_mse_part(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(Y), _ptr(L.contiguous()), grad_scale,
+                               _ptr(loss), _ptr(stash), C.byref(gs), _ptr(ws), ws_bytes, _stream(), part)
+    _lib.check(rc, "wgnn_bwd_mse_part(%d)" % part)
+
+
 class GCNGRUFunction(torch.autograd.Function):
     """Y = GCN_GRU(A, X; 8 params).  Gradients flow to the parameters only: the reference's
     adjacency and inputs do not require grad (src/main.py:26, src/step4_sequence_preparer.py:58)."""

@@ -1,5 +1,5 @@
 """Host-side mirror of the reference's training-loop body (src/main.py:64-80) on flat buffers:
-forward -> MSE -> backward -> (data-parallel all-reduce) -> Adam, every op a C-ABI call.
+forward -> MSE + backward (wgnn_bwd_mse_part) -> (data-parallel all-reduce) -> Adam, every op a C-ABI call.
 
 Data parallel: windows are independent, so each rank runs its own shard of
 windows; the 8 gradients live in ONE flat fp32 bucket (167 440 floats at S=34) that is summed
@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 from .distributed import allreduce_flat_
-from .functional import adam_step_, gcn_gru_backward_raw, gcn_gru_forward_raw, mse_loss_grad
+from .functional import adam_step_, gcn_gru_backward_mse_raw, gcn_gru_forward_raw
 from .modules import GCN_GRU
 
 
@@ -42,8 +42,8 @@ class TrainStep:
     def forward_backward(self, A, X, L):
         """src/main.py:66,72,79: returns (loss, Y); gradients land in the flat bucket."""
         Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True)
-        loss, dY = mse_loss_grad(Y, L, grad_scale=1.0 / self.world)
-        gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views)
+        loss = torch.empty((), dtype=torch.float32, device=Y.device)
+        gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0 / self.world)
         return loss, Y
 
     def step(self, A, X, L):
@@ -52,11 +52,12 @@ class TrainStep:
             # their all-reduce runs on RCCL's stream while part 2 (dg GEMM + GCN backward, ~30 % of the
             # step) still computes; the 364 conv gradients follow in a second, tiny all-reduce.
             Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True)
-            loss, dY = mse_loss_grad(Y, L, grad_scale=1.0 / self.world)
-            gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views, part=1 | 4)
+            loss = torch.empty((), dtype=torch.float32, device=Y.device)
+            gs = 1.0 / self.world
+            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=1 | 4)
             n_conv = sum(g.numel() for g in self.g_views[:4])
             work = torch.distributed.all_reduce(self.flat_g[n_conv:], group=self.group, async_op=True)
-            gcn_gru_backward_raw(d, A, X, self.p_views, Y, dY, stash, self.g_views, part=2)
+            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=2)
             allreduce_flat_(self.flat_g[:n_conv], self.group)
             work.wait()
         else:
