@@ -113,7 +113,7 @@ int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float*
                               hipStream_t st);
 // register-chained split-fp16 variants (gcnx.hip)
 size_t gcnx2_bwd_partial_floats(int ntiles);
-int gcnx_bwd_grid(int ntiles);
+int gcnx_bwd_grid(int ntiles, int S);
 // g_planes: fp16 hi plane [ntiles][ldg] followed by the lo plane; column S*13 holds 1.0, later columns 0
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, hipStream_t st);

@@ -329,10 +329,10 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 // scales[1] at the end.
 // 12 waves per backward block, one block per CU: the chain of small dependent products is latency-bound, and
 // three waves per SIMD (166 VGPRs) hide more of it than two (measured 181 vs 198 us; 4-wave blocks, 2 per CU).
-constexpr int BWD_WAVES = 12;
+constexpr int bwd_waves(int NT) { return 12; }   // (16 waves at 128 VGPRs spill: 291 vs 181 us)
 
 template <int NT, bool X3>
-__global__ void __launch_bounds__(64 * BWD_WAVES) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
+__global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const _Float16* __restrict__ gact, int ld_g,
@@ -344,6 +344,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcnx_bwd_kernel(int ntiles, in
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
   __shared__ __attribute__((aligned(16))) h8 sCA[2 * NF * 64];   // [frag][hi|lo][lane]
   __shared__ __attribute__((aligned(16))) h8 sCT[2 * NF * 64];
+  constexpr int BWD_WAVES = bwd_waves(NT);
   __shared__ __attribute__((aligned(16))) float sbuf[BWD_WAVES * 2 * SP * XS];
   static_assert(2 * SP * XS >= PART, "the per-wave staging buffer doubles as its reduction row");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -555,16 +556,16 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcnx_bwd_kernel(int ntiles, in
   }
 }
 
-int grid_x(int ntiles) {
-  int g = cdiv_i(ntiles, BWD_WAVES);
+int grid_x(int ntiles, int S) {
+  int g = cdiv_i(ntiles, bwd_waves((S + 15) / 16));
   const int cap = 256;                              // one block per CU, persistent over the tiles
   return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
 }  // namespace
 
-size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)grid_x(ntiles) * PART; }
-int gcnx_bwd_grid(int ntiles) { return grid_x(ntiles); }
+size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)256 * PART; }
+int gcnx_bwd_grid(int ntiles, int S) { return grid_x(ntiles, S); }
 
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, hipStream_t st) {
@@ -602,15 +603,15 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const fl
   const _Float16* g = (const _Float16*)g_planes;   // hi plane carries the sign: g > 0 <=> hi > 0
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
-  const dim3 grid(grid_x(ntiles));
+  const dim3 grid(grid_x(ntiles, S));
 #define BWD_CASE(NT)                                                                                               \
   if (x3)                                                                                                          \
     PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                            \
-                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(64 * BWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, g,  \
+                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, W1, b1, W2, g,  \
                                    ldg, dg, scales, scale_in, partial));                                           \
   else                                                                                                             \
     PROF_LAUNCH("gcnx_bwd_kernel<" #NT ",f16>", fl, by, st,                                                        \
-                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(64 * BWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, g, \
+                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, W1, b1, W2, g, \
                                    ldg, dg, scales, scale_in, partial))
   switch ((S + 15) / 16) {
     case 1: BWD_CASE(1); break;
