@@ -155,7 +155,7 @@ def main():
         dt = float(tmax.item())
 
     # ---- per-kernel pass (same workload, hipEvents inside the library) for the roofline object
-    roofline, forward, kernels = None, None, None
+    roofline, forward, kernels, mfma = None, None, None, None
     if rank == 0:
         _lib.profile_enable(True)
         for _ in range(args.steps):
@@ -189,6 +189,17 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": tr["bytes_per_launch"] if tr else None,
                         "avg_launch_us": round(avg_s * 1e6, 2)}
+        # MFMA side of the picture (north-star: "HBM GB/s and MFMA utilisation against the roofline"): the GEMM with
+        # the most time; f16x3 issues 3 fp16 MFMA passes per algorithmic FLOP
+        gemms = [r for r in recs if r["name"].startswith(("pgemm_", "gemm_f32")) and r["flops"] > 0]
+        mfma = None
+        if gemms:
+            gk = gemms[0]
+            passes = 3.0 if (args.math == "f16x3" and gk["name"].startswith("pgemm_")) else 1.0
+            peak_k = MFMA_PEAK_TFLOPS["f32" if gk["name"].startswith("gemm_f32") else args.math]
+            tf = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
+            mfma = {"kernel": gk["name"], "algorithmic_TFLOPs": round(tf, 1), "issued_TFLOPs": round(tf * passes, 1),
+                    "peak": peak_k, "frac_issued": round(tf * passes / peak_k, 4)}
         roofline["algorithmic_bytes_per_launch"] = round(d["bytes"] / d["launches"])
         roofline["hbm_GBs_algorithmic"] = round(d["bytes"] / d["launches"] / avg_s / 1e9, 1)
         if tr:
@@ -228,6 +239,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "math": args.math},
             "loss": round(float(loss), 6),
             "roofline": roofline,
+            "mfma": mfma,
             "forward": forward,
             "kernels": kernels,
         }
