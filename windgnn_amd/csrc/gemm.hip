@@ -22,10 +22,11 @@ struct GemmP {
   float* partial;
 };
 
-// stage a [BK][128] k-major LDS tile from a global operand.  rows = m (or n) index, origin r0.
-// kcontig: element (r,k) at P[r*ld + k]; else at P[k*ld + r].
+// One thread's share (8 values) of a [BK][128] k-major LDS tile, fetched from a global operand into registers
+// (fetch) and written to LDS later (commit), so that the loads of step k+1 fly under the MFMAs of step k.
+// rows = m (or n) index, origin r0.  kcontig: element (r,k) at P[r*ld + k]; else at P[k*ld + r].
 template <bool IS_B>
-__device__ __forceinline__ void stage(float* T, const GemmP& p, const float* P, int ld, int kcontig, int r0,
+__device__ __forceinline__ void fetch(float (&v)[8], const GemmP& p, const float* P, int ld, int kcontig, int r0,
                                       int nrows, int k0, int kend) {
   const int tid = threadIdx.x;
   if (kcontig) {
@@ -33,10 +34,8 @@ __device__ __forceinline__ void stage(float* T, const GemmP& p, const float* P, 
     const int gr = r0 + r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      int k = k0 + kc + j;
-      float v = 0.f;
-      if (gr < nrows && k < kend) v = P[(size_t)gr * ld + k];
-      T[(kc + j) * LDT + r] = v;
+      const int k = k0 + kc + j;
+      v[j] = (gr < nrows && k < kend) ? P[(size_t)gr * ld + k] : 0.f;
     }
   } else {
     const int kk = tid >> 4, rc = (tid & 15) * 8;
@@ -53,12 +52,24 @@ __device__ __forceinline__ void stage(float* T, const GemmP& p, const float* P, 
     const int ndata = nrows - (IS_B ? p.ones_col : 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      int gr = r0 + rc + j;
-      float v = 0.f;
-      if (IS_B && p.ones_col && gr == nrows - 1) v = kvalid ? 1.f : 0.f;
-      else if (krow && gr < ndata) v = P[rowoff + gr];
-      T[kk * LDT + rc + j] = v;
+      const int gr = r0 + rc + j;
+      float x = 0.f;
+      if (IS_B && p.ones_col && gr == nrows - 1) x = kvalid ? 1.f : 0.f;
+      else if (krow && gr < ndata) x = P[rowoff + gr];
+      v[j] = x;
     }
+  }
+}
+__device__ __forceinline__ void commit(float* T, const float (&v)[8], int kcontig) {
+  const int tid = threadIdx.x;
+  if (kcontig) {
+    const int r = tid >> 1, kc = (tid & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) T[(kc + j) * LDT + r] = v[j];
+  } else {
+    const int kk = tid >> 4, rc = (tid & 15) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) T[kk * LDT + rc + j] = v[j];
   }
 }
 
@@ -92,6 +103,11 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   int since = 0;
+  float va[8], vb[8];
+  if (kbeg < kend) {
+    fetch<false>(va, p, p.A, p.lda, p.a_kc, m0, p.M, kbeg, kend);
+    fetch<true>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg, kend);
+  }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     if (since == 512 / BK) {
 #pragma unroll
@@ -105,9 +121,13 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
       since = 0;
     }
     ++since;
-    stage<false>(As, p, p.A, p.lda, p.a_kc, m0, p.M, k0, kend);
-    stage<true>(Bs, p, p.B, p.ldb, p.b_kc, n0, p.N, k0, kend);
+    commit(As, va, p.a_kc);
+    commit(Bs, vb, p.b_kc);
     __syncthreads();
+    if (k0 + BK < kend) {               // next step's operands: in flight under this step's MFMAs
+      fetch<false>(va, p, p.A, p.lda, p.a_kc, m0, p.M, k0 + BK, kend);
+      fetch<true>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + BK, kend);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a0 = As[(kk + lk) * LDT + wm + li];
