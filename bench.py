@@ -102,8 +102,8 @@ def cpu_baseline(budget_s=12.0, Bc=1024):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU (weak scaling); default 4096 (128 for c5)")
     ap.add_argument("--math", default="f16x3", choices=["f32", "f16x3", "f16"])
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
