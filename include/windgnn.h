@@ -150,6 +150,14 @@ int wgnn_gcn_layer_bwd(int32_t ntiles, int32_t S, int32_t F, const float* A, con
                        const float* W, const float* out, const float* dout, float* dW, float* db,
                        float* dX, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same layer over a CSR adjacency (`csr`: the WGNN_ADJ_CSR buffer described at wgnn_adj_format), any S. */
+size_t wgnn_gcn_layer_csr_workspace_bytes(int32_t ntiles, int32_t S, int32_t F);
+int wgnn_gcn_layer_csr_fwd(int32_t ntiles, int32_t S, int32_t F, int32_t nnz, const void* csr, const float* X,
+                           const float* W, const float* b, float* out, void* stream);
+int wgnn_gcn_layer_csr_bwd(int32_t ntiles, int32_t S, int32_t F, int32_t nnz, const void* csr, const float* X,
+                           const float* W, const float* out, const float* dout, float* dW, float* db,
+                           float* dX, void* workspace, size_t workspace_bytes, void* stream);
+
 /* loss[0] = mean((Y-L)^2) over n elements; dY = 2 (Y-L) * grad_scale / n.
  * (grad_scale = 1/world_size under data parallel so that summed shard grads equal the
  * big-batch gradient.)  workspace: >= 4096 bytes. */

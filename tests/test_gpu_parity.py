@@ -435,3 +435,28 @@ def test_fused_loss_backward_equals_loss_then_backward(S, T, B, H, math):
     gcn_gru_backward_mse_raw(d, A.to(dev), X.to(dev), params, Y, L.to(dev), stash, grads2, loss, 0.5, part=2)
     for a, b in zip(grads, grads2):
         assert rel_to_max(2.0 * b.cpu(), a.cpu()) <= 1e-6
+
+
+def test_graph_conv_layer_with_csr_adjacency():
+    """GraphConvLayer alone (src/step5_gcn_layer_model.py) over a 150-station k-NN graph in CSR, including dX."""
+    from windgnn_amd import GraphConvLayer
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    dev = _dev()
+    torch.manual_seed(6)
+    S = 150
+    csr = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=2), 6))
+    A = csr.dense()
+    X = torch.rand(2, 3, S, 13, requires_grad=True)
+    layer = GraphConvLayer(13, 13)
+    ref_out = torch.relu(torch.matmul(torch.matmul(A.double(), X.double()), layer.weight.double()) + layer.bias.double())
+    dout = torch.rand_like(ref_out)
+    gX, gW, gb = torch.autograd.grad(ref_out, [X, layer.weight, layer.bias], dout)
+    layer_d = GraphConvLayer(13, 13).to(dev)
+    layer_d.load_state_dict(layer.state_dict())
+    Xd = X.detach().to(dev).requires_grad_(True)
+    out = layer_d(csr.to(dev), Xd)
+    out.backward(dout.float().to(dev))
+    assert max_abs(out.detach().cpu(), ref_out) <= 1e-5
+    assert rel_to_max(Xd.grad.cpu(), gX) <= 1e-5
+    assert rel_to_max(layer_d.weight.grad.cpu(), gW) <= 1e-5
+    assert rel_to_max(layer_d.bias.grad.cpu(), gb) <= 1e-5

@@ -415,6 +415,27 @@ int wgnn_gcn_layer_bwd(int32_t ntiles, int32_t S, int32_t F, const float* A, con
   return launch_gcn1_bwd(ntiles, S, A, X, W, out, dout, dW, db, dX, (float*)workspace, (hipStream_t)stream);
 }
 
+size_t wgnn_gcn_layer_csr_workspace_bytes(int32_t ntiles, int32_t S, int32_t F) {
+  if (ntiles < 1 || S < 1 || F != 13 || (int64_t)ntiles * S * F >= (1ll << 31)) return 0;
+  return sizeof(float) * gcn1_csr_bwd_ws_floats(ntiles, S);
+}
+
+int wgnn_gcn_layer_csr_fwd(int32_t ntiles, int32_t S, int32_t F, int32_t nnz, const void* csr, const float* X,
+                           const float* W, const float* b, float* out, void* stream) {
+  if (ntiles < 1 || S < 1 || F != 13 || nnz < 1 || (int64_t)ntiles * S * F >= (1ll << 31)) return WGNN_ERR_SHAPE;
+  if (!csr || !X || !W || !b || !out) return WGNN_ERR_NULL;
+  return launch_gcn1_csr_fwd(ntiles, S, nnz, csr, X, W, b, out, (hipStream_t)stream);
+}
+
+int wgnn_gcn_layer_csr_bwd(int32_t ntiles, int32_t S, int32_t F, int32_t nnz, const void* csr, const float* X,
+                           const float* W, const float* out, const float* dout, float* dW, float* db, float* dX,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (ntiles < 1 || S < 1 || F != 13 || nnz < 1 || (int64_t)ntiles * S * F >= (1ll << 31)) return WGNN_ERR_SHAPE;
+  if (!csr || !X || !W || !out || !dout || !dW || !db || !workspace) return WGNN_ERR_NULL;
+  if (workspace_bytes < wgnn_gcn_layer_csr_workspace_bytes(ntiles, S, F)) return WGNN_ERR_WORKSPACE;
+  return launch_gcn1_csr_bwd(ntiles, S, nnz, csr, X, W, out, dout, dW, db, dX, (float*)workspace, (hipStream_t)stream);
+}
+
 int wgnn_mse_loss_grad(const float* Y, const float* L, int64_t n, float grad_scale, float* dY, float* loss,
                        void* workspace, size_t workspace_bytes, void* stream) {
   if (!Y || !L || !loss || !workspace) return WGNN_ERR_NULL;

@@ -153,6 +153,11 @@ int launch_gru_gen_fwd(int B, int T, int H, const float* GI, int ldgi, const flo
                        float* gates, float* gh, hipStream_t st);
 int launch_gru_gen_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
                        float* dGI, float* dGH, int ldd, float* dhz, float* dhw, hipStream_t st);
+size_t gcn1_csr_bwd_ws_floats(int ntiles, int S);
+int launch_gcn1_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W, const float* b,
+                        float* out, hipStream_t st);
+int launch_gcn1_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W, const float* out,
+                        const float* dout, float* dW, float* db, float* dX, float* ws, hipStream_t st);
 int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W,
                     const float* b, float* out, hipStream_t st);
 size_t gcn1_bwd_partial_floats(int ntiles);

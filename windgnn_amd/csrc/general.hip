@@ -302,6 +302,21 @@ __global__ void gru_cell_bwd_x3_kernel(int B, int T, int t, int H, const float* 
   dhz[i] = dh * z;
 }
 
+// Out[tile][s][:] = (M In[tile])[s][:]   (the layer's dX = A^T (dZ W^T) when GraphConvLayer is used on its own)
+__global__ void __launch_bounds__(ROWS) csr_spmm_kernel(int ntiles, int S, Csr M, const float* __restrict__ In,
+                                                        float* __restrict__ Out) {
+  const int s = blockIdx.x * ROWS + threadIdx.x;
+  if (s >= S) return;
+  const size_t I = (size_t)S * F13;
+  for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+    float p[F13];
+    spmv_row(M, s, In + (size_t)tile * I, p);
+    float* o = Out + (size_t)tile * I + (size_t)s * F13;
+#pragma unroll
+    for (int f = 0; f < F13; ++f) o[f] = p[f];
+  }
+}
+
 Csr csr_of(const void* blob, int S, int nnz, bool transposed) {
   const int* w = (const int*)blob + (transposed ? (size_t)S + 1 + 2 * (size_t)nnz : 0);
   Csr c;
@@ -455,5 +470,37 @@ int launch_gru_gen_bwd_x3(int B, int T, int H, const void* whhT_planes, int np_h
       if (rc != WGNN_OK) return rc;
     }
   }
+  return WGNN_OK;
+}
+
+// ---- one GraphConvLayer with a CSR adjacency (wgnn_gcn_layer_csr_fwd / _bwd) ------------------------
+size_t gcn1_csr_bwd_ws_floats(int ntiles, int S) { return (size_t)ntiles * S * F13 + gcn_csr_bwd_partial_floats(); }
+
+int launch_gcn1_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W, const float* b,
+                        float* out, hipStream_t st) {
+  const Csr A = csr_of(csr, S, nnz, false);
+  const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
+  const size_t I = (size_t)S * F13;
+  hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(ROWS), 0, st, ntiles, S, A, X, I, W, b, out, I,
+                     (_Float16*)nullptr, (_Float16*)nullptr);
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+// dW, db (overwritten) and, if dX != nullptr, dX = A^T ((dout * (out > 0)) W^T); ws: gcn1_csr_bwd_ws_floats()
+int launch_gcn1_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W, const float* out,
+                        const float* dout, float* dW, float* db, float* dX, float* ws, hipStream_t st) {
+  const Csr A = csr_of(csr, S, nnz, false), AT = csr_of(csr, S, nnz, true);
+  const size_t I = (size_t)S * F13;
+  float* du = ws;
+  float* partial = ws + (size_t)ntiles * I;
+  hipLaunchKernelGGL((csr_layer_bwd_kernel<true>), dim3(GEN_BLOCKS), dim3(ROWS), 0, st, ntiles, S, A, AT, X, I, out,
+                     (const _Float16*)nullptr, I, dout, I, W, du, (const float*)nullptr, partial);
+  WGNN_CHECK_LAUNCH();
+  int rc = launch_gcn_partial_reduce(partial, GEN_BLOCKS, nullptr, nullptr, dW, db, st);   // the "layer 2" slots
+  if (rc != WGNN_OK || !dX) return rc;
+  const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
+  hipLaunchKernelGGL(csr_spmm_kernel, grid, dim3(ROWS), 0, st, ntiles, S, AT, du, dX);
+  WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

@@ -153,28 +153,39 @@ class GraphConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, X, W, b):
         lib = _lib.load()
-        _require_gpu(A, X, W, b)
-        A, X, W, b = A.contiguous(), X.contiguous(), W.contiguous(), b.contiguous()
+        _require_gpu(X, W, b)
+        A, fmt, nnz = _adj(A)
+        X, W, b = X.contiguous(), W.contiguous(), b.contiguous()
         S, F = X.shape[-2], X.shape[-1]
-        if A.shape != (S, S):
+        if fmt == _lib.ADJ_DENSE and A.shape != (S, S):
             raise RuntimeError("windgnn_amd: adjacency %s does not match %d stations" % (tuple(A.shape), S))
         nt = X.numel() // (S * F)
         out = torch.empty_like(X)
-        rc = lib.wgnn_gcn_layer_fwd(nt, S, F, _ptr(A), _ptr(X), _ptr(W), _ptr(b), _ptr(out), _stream())
+        if fmt == _lib.ADJ_CSR:
+            rc = lib.wgnn_gcn_layer_csr_fwd(nt, S, F, nnz, _ptr(A), _ptr(X), _ptr(W), _ptr(b), _ptr(out), _stream())
+        else:
+            rc = lib.wgnn_gcn_layer_fwd(nt, S, F, _ptr(A), _ptr(X), _ptr(W), _ptr(b), _ptr(out), _stream())
         _lib.check(rc, "wgnn_gcn_layer_fwd")
         ctx.save_for_backward(A, X, W, out)
-        ctx.dims = (nt, S, F)
+        ctx.dims = (nt, S, F, fmt, nnz)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         A, X, W, out = ctx.saved_tensors
-        nt, S, F = ctx.dims
+        nt, S, F, fmt, nnz = ctx.dims
         dout = dout.contiguous()
         dW = torch.empty_like(W)
         db = torch.empty(F, dtype=torch.float32, device=X.device)
         dX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
+        if fmt == _lib.ADJ_CSR:
+            nbytes = lib.wgnn_gcn_layer_csr_workspace_bytes(nt, S, F)
+            ws = _Workspace.get(X.device, nbytes)
+            rc = lib.wgnn_gcn_layer_csr_bwd(nt, S, F, nnz, _ptr(A), _ptr(X), _ptr(W), _ptr(out), _ptr(dout), _ptr(dW),
+                                            _ptr(db), _ptr(dX), _ptr(ws), nbytes, _stream())
+            _lib.check(rc, "wgnn_gcn_layer_csr_bwd")
+            return None, dX, dW, db
         nbytes = lib.wgnn_gcn_layer_workspace_bytes(nt, S, F)
         ws = _Workspace.get(X.device, nbytes)
         rc = lib.wgnn_gcn_layer_bwd(nt, S, F, _ptr(A), _ptr(X), _ptr(W), _ptr(out), _ptr(dout), _ptr(dW), _ptr(db),
