@@ -6,11 +6,19 @@ gradient all-reduce when N > 1) on synthetic 34-station hourly windows.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").  Inputs are resident in HBM before the
-timed region; every arithmetic op of the step is a libwindgnn_hip.so kernel."""
+timed region; every arithmetic op of the step is a libwindgnn_hip.so kernel.
+
+Order of a default N = 1 run: (1) two short child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then
+WRITE_SIZE: the counters cannot share a pass) measure the HBM traffic of every kernel of THIS build, before this
+process touches the GPU; (2) warm-up + the timed steps; (3) a per-kernel pass with hipEvents inside the library;
+(4) forward-only timing; (5) the exact-fp32 mode on the same workload (secondary value); (6) the CPU baselines."""
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,17 +34,44 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
 BOUND_HBM_PREFIXES = ("mse_", "adam_", "amax_", "splitk_reduce", "tn_reduce", "split_weight", "gcn_partial", "csr_", "gru_cell")
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.py), or None."""
+def committed_traffic():
+    """Fallback only: the newest committed PMC summary (profiles/*traffic*.json), or ({}, None)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), key=os.path.getmtime, reverse=True):
         try:
-            k = json.load(open(path))["kernels"].get(kernel)
+            return json.load(open(path))["kernels"], os.path.basename(path)
         except Exception:
-            k = None
-        if k:
-            return {"bytes_per_launch": round(k["bytes_per_launch"]), "source": os.path.basename(path)}
-    return None
+            continue
+    return {}, None
+
+
+def measure_traffic_live(args):
+    """HBM bytes per launch of every kernel, measured NOW: this script re-run as a child (3 steps) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and again with WRITE_SIZE (MI355X_MICROARCH.md, HBM / rocprofv3:
+    separate passes; KiB units; gfx950 reads x2).  Returns ({kernel: {...}}, source string) or ({}, reason)."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {}, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+        return {}, "already running under a profiler"
+    from tools.pmc_traffic import traffic
+    tmp = tempfile.mkdtemp(prefix="wgnn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-child", "--steps", "3", "--warmup", "1",
+             "--math", args.math, "--workload", args.workload] + (["--batch", str(args.batch)] if args.batch else [])
+    try:
+        for counter, sub in (("FETCH_SIZE", "F"), ("WRITE_SIZE", "W")):
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d",
+                                os.path.join(tmp, sub), "--"] + child, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=420)
+            if r.returncode != 0:
+                return {}, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-200:])
+        k = traffic(os.path.join(tmp, "F"), os.path.join(tmp, "W"))
+        return k, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (reads x2, KiB units)"
+    except Exception as e:      # a profiler problem must not cost the bench line
+        return {}, "live measurement failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def adjacency_34():
@@ -74,9 +109,21 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(budget_s=12.0, Bc=1024):
-    """The oracle (a torch-CPU restatement of the reference ops) timed on this host: same step
-    (forward + MSE + hand-derived backward + Adam), fp32, batched, all host threads."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=10.0, Bc=1024, faithful_budget_s=8.0):
+    """The oracle (a torch-CPU restatement of the reference ops) timed on this host, two variants:
+    batched   -- one [Bc,T,S,13] call per step: forward + MSE + hand-derived backward + Adam;
+    faithful  -- what src/main.py:65-80 does: a loop of reference-shaped B = 1 calls, each followed by its own
+                 optimiser step (one window per step)."""
     from oracle import windgnn_oracle as orc
     torch.set_num_threads(host_threads())
     A = adjacency_34()
@@ -94,9 +141,25 @@ def cpu_baseline(budget_s=12.0, Bc=1024):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 50:
             break
+    p1 = orc.init_params(S, F, H, seed=0)
+    st1 = orc.adam_init(p1)
+    for b in range(3):                                  # warm-up
+        orc.train_step(A, X[b:b + 1], L[b:b + 1], p1)
+    m, t1 = 0, time.perf_counter()
+    while True:
+        b = m % Bc
+        _, _, gr = orc.train_step(A, X[b:b + 1], L[b:b + 1], p1)
+        p1 = orc.adam_step(p1, gr, st1)
+        m += 1
+        dt1 = time.perf_counter() - t1
+        if dt1 >= faithful_budget_s:
+            break
+    shape = "S=34,T=24,H=102 fp32, fwd+MSE+bwd+Adam, oracle/windgnn_oracle.py on torch %s CPU" % torch.__version__
     return {"value": round(n * Bc / dt, 1), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d steps of B=%d windows (S=34,T=24,H=102 fp32, fwd+MSE+bwd+Adam), oracle/windgnn_oracle.py "
-                      "on torch %s CPU, %.1f s" % (n, Bc, torch.__version__, dt)}
+            "cpu_model": cpu_model(),
+            "sample": "batched: %d steps of B=%d windows (%s), %.1f s" % (n, Bc, shape, dt),
+            "faithful": {"value": round(m / dt1, 1), "unit": "windows/s",
+                         "sample": "%d sequential B=1 steps as src/main.py:65-80 (%s), %.1f s" % (m, shape, dt1)}}
 
 
 def main():
@@ -109,6 +172,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
                     help="c3: 34 stations, the headline config; c5: 4096-station k-NN CSR stress config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes (N = 1 only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the exact-fp32 secondary measurement")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,6 +185,21 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d != WORLD_SIZE %d" % (args.gpus, world))
+    ndev = torch.cuda.device_count()                    # does not initialise the GPU
+    if local_rank >= ndev:
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPU(s) visible: one process per GPU, launch with "
+                         "--nproc-per-node <= %d" % (local_rank, ndev, ndev))
+
+    traffic, traffic_src = {}, None
+    if world == 1 and not args.traffic_child:
+        if not args.no_traffic:
+            traffic, traffic_src = measure_traffic_live(args)
+        if not traffic:
+            why = traffic_src
+            traffic, traffic_src = ({}, None) if args.workload != "c3" or args.math != "f16x3" else committed_traffic()
+            if traffic_src:
+                traffic_src = "committed file %s (%s)" % (traffic_src, why or "--no-traffic")
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -149,13 +230,16 @@ def main():
         loss, _ = trainer.step(A, X, L)
     barrier()
     dt = time.perf_counter() - t0
+    if args.traffic_child:
+        return
+    trainer.check()                                     # fp16-plane modes: nothing left fp16's range
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     # ---- per-kernel pass (same workload, hipEvents inside the library) for the roofline object
-    roofline, forward, kernels, mfma = None, None, None, None
+    roofline, forward, kernels, mfma, path, secondary = None, None, None, None, None, None
     if rank == 0:
         _lib.profile_enable(True)
         for _ in range(args.steps):
@@ -164,9 +248,14 @@ def main():
         recs = _lib.profile_read()
         _lib.profile_enable(False)
         recs.sort(key=lambda r: -r["ms"])
-        kernels = [{"name": r["name"], "launches_per_step": r["launches"] / args.steps,
-                    "avg_us": round(1e3 * r["ms"] / max(r["launches"], 1), 2),
-                    "ms_per_step": round(r["ms"] / args.steps, 4)} for r in recs]
+        kernels = []
+        for r in recs:
+            tr = traffic.get(r["name"])
+            kernels.append({"name": r["name"], "launches_per_step": r["launches"] / args.steps,
+                            "avg_us": round(1e3 * r["ms"] / max(r["launches"], 1), 2),
+                            "ms_per_step": round(r["ms"] / args.steps, 4),
+                            "algorithmic_bytes_per_launch": round(r["bytes"] / max(r["launches"], 1)),
+                            "traffic_bytes_per_launch": round(tr["bytes_per_launch"]) if tr else None})
         d = recs[0]
         avg_s = d["ms"] / d["launches"] * 1e-3
         # which roofline binds this kernel: time its ALGORITHMIC bytes need at the HBM peak vs the time its
@@ -175,24 +264,26 @@ def main():
         t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
         t_mfma = d["flops"] / (eff_peak * 1e12)
         bound = "hbm" if (d["name"].startswith(BOUND_HBM_PREFIXES) or t_hbm >= t_mfma) else "mfma"
-        tr = measured_traffic(d["name"]) if args.workload == "c3" else None   # the PMC passes are of the c3 workload
+        tr = traffic.get(d["name"])
+        trb = round(tr["bytes_per_launch"]) if tr else None
         if bound == "mfma":
             ach = d["flops"] / d["launches"] / avg_s / 1e12
             peak = MFMA_PEAK_TFLOPS[args.math]
             roofline = {"kernel": d["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                        "traffic": tr["bytes_per_launch"] if tr else None,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": trb,
                         "avg_launch_us": round(avg_s * 1e6, 2)}
         else:
             ach = d["bytes"] / d["launches"] / avg_s / 1e9
             roofline = {"kernel": d["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": tr["bytes_per_launch"] if tr else None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": trb,
                         "avg_launch_us": round(avg_s * 1e6, 2)}
+        roofline["algorithmic_bytes_per_launch"] = round(d["bytes"] / d["launches"])
+        roofline["traffic_source"] = traffic_src
+        if trb:
+            roofline["traffic_vs_algorithmic"] = round(trb / (d["bytes"] / d["launches"]), 3)
         # MFMA side of the picture (north-star: "HBM GB/s and MFMA utilisation against the roofline"): the GEMM with
         # the most time; f16x3 issues 3 fp16 MFMA passes per algorithmic FLOP
         gemms = [r for r in recs if r["name"].startswith(("pgemm_", "gemm_f32")) and r["flops"] > 0]
-        mfma = None
         if gemms:
             gk = gemms[0]
             passes = 3.0 if (args.math == "f16x3" and gk["name"].startswith("pgemm_")) else 1.0
@@ -200,10 +291,19 @@ def main():
             tf = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
             mfma = {"kernel": gk["name"], "algorithmic_TFLOPs": round(tf, 1), "issued_TFLOPs": round(tf * passes, 1),
                     "peak": peak_k, "frac_issued": round(tf * passes / peak_k, 4)}
-        roofline["algorithmic_bytes_per_launch"] = round(d["bytes"] / d["launches"])
-        roofline["hbm_GBs_algorithmic"] = round(d["bytes"] / d["launches"] / avg_s / 1e9, 1)
-        if tr:
-            roofline["traffic_source"] = tr["source"]
+        # ---- the path as a whole: 2X + 2Y + L per window, fwd + bwd with recompute
+        alg_step = float(B) * T * (2 * S * F + 3 * H) * 4.0
+        step_s = dt / args.steps
+        path = {"algorithmic_bytes_per_step": round(alg_step),
+                "fwd_bwd_GBs": round(alg_step / step_s / 1e9, 1),
+                "fwd_bwd_frac": round(alg_step / step_s / 1e9 / HBM_PEAK_GBS, 4)}
+        if traffic:
+            tot = sum(k["traffic_bytes_per_launch"] * k["launches_per_step"] for k in kernels
+                      if k["traffic_bytes_per_launch"])
+            tot += sum(v["bytes_per_launch"] for n, v in traffic.items() if n == "adam_kernel")   # the optimiser step
+            path["traffic_bytes_per_step"] = round(tot)
+            path["traffic_vs_algorithmic"] = round(tot / alg_step, 2)
+            path["traffic_GBs"] = round(tot / step_s / 1e9, 1)
         # forward-only timing: north-star "fused forward vs HBM roofline" (52 224 algorithmic B/window)
         from windgnn_amd.functional import gcn_gru_forward_raw
         torch.cuda.synchronize()
@@ -218,6 +318,23 @@ def main():
         forward = {"us": round(fwd_s * 1e6, 1), "algorithmic_GBs": round(fwd_bytes / fwd_s / 1e9, 1),
                    "hbm_frac": round(fwd_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
                    "windows_per_s": round(B / fwd_s, 1)}
+        # ---- secondary: the same workload in the exact-fp32 mode (bitwise fp32 fmaf chains, fp32 MFMA)
+        if world == 1 and args.math != "f32" and args.workload == "c3" and not args.no_secondary:
+            m32 = GCN_GRU(F, F, F, S * F, H, math="f32").to(dev)
+            t32 = TrainStep(m32)
+            n32 = max(5, min(args.steps, 30))
+            for _ in range(3):
+                t32.step(A, X, L)
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            for _ in range(n32):
+                t32.step(A, X, L)
+            torch.cuda.synchronize()
+            d32 = time.perf_counter() - s0
+            secondary = {"dtype": "f32", "value": round(B * n32 / d32, 1), "unit": "windows/s",
+                         "ms_per_step": round(1e3 * d32 / n32, 4), "steps": n32,
+                         "note": "same workload and step, WGNN_MATH_F32 (fp32-input MFMA, bitwise fp32 fmaf chains)"}
+            del t32, m32
 
     if rank == 0:
         out = {
@@ -239,8 +356,10 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "math": args.math},
             "loss": round(float(loss), 6),
             "roofline": roofline,
+            "path": path,
             "mfma": mfma,
             "forward": forward,
+            "exact_f32": secondary,
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":

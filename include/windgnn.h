@@ -16,7 +16,9 @@
  * Conventions
  *   - extern "C", plain pointers and sizes only; no torch / C++ types.
  *   - Every data pointer is DEVICE memory owned by the caller (workspace and stash included);
- *     the library allocates nothing persistent, keeps no mutable global state, frees nothing.
+ *     the library allocates nothing persistent and frees nothing.  Process-wide state is limited to: a
+ *     per-kernel "opted into > 64 KB of dynamic LDS on device d" bit set (written once per device, atomically)
+ *     and the wgnn_profile_* measurement aid (off by default, not thread-safe).
  *   - All tensors are contiguous fp32 in the reference's layouts:
  *       A [S,S] row-major (or CSR, see wgnn_adj_format), X [B,T,S,F] (F fastest), Y [B,T,H], L [B,T,H],
  *       conv*.weight [F,F] (in,out), conv*.bias [F], w_ih [3H, S*F], w_hh [3H,H], b_ih/b_hh [3H],
@@ -36,7 +38,19 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 100 /* 0.1.0 */
+#define WGNN_VERSION 110 /* 0.1.1 */
+
+/* Status block: the first 256 bytes of every `workspace` passed to wgnn_fwd / wgnn_bwd* belong to the library as a
+ * sticky status area that kernels only ever OR into; word 0 (uint32) holds the bits below.  The caller zeroes the
+ * workspace once when it allocates it, may read word 0 whenever it synchronises anyway, and clears it after
+ * handling an error.  The fp16-plane math modes (WGNN_MATH_F16X3 / WGNN_MATH_F16) hold activations and weights as
+ * fp16 (hi [+ lo]) and cannot represent magnitudes >= 65520; the reference's fp32 path has no such limit, so
+ * instead of producing inf/NaN (or, behind a ReLU, silently 0) the kernels report it here.  WGNN_MATH_F32 never
+ * sets a bit. */
+#define WGNN_STATUS_BYTES 256
+#define WGNN_STATUS_ACT_RANGE 1u    /* a GCN pre-activation left fp16's range (or was NaN) in the forward */
+#define WGNN_STATUS_WEIGHT_RANGE 2u /* a GRU weight / bias left fp16's range */
+#define WGNN_STATUS_GRAD_NONFINITE 4u /* a final gradient is inf / NaN */
 
 typedef enum wgnn_status {
   WGNN_OK = 0,
@@ -45,7 +59,8 @@ typedef enum wgnn_status {
   WGNN_ERR_DTYPE = -3,       /* unsupported dtype / math mode */
   WGNN_ERR_WORKSPACE = -4,   /* workspace or stash smaller than wgnn_*_bytes() says */
   WGNN_ERR_UNSUPPORTED = -5, /* e.g. a dense adjacency with S > 64 (pass it as CSR) */
-  WGNN_ERR_HIP = -6          /* a HIP runtime call or kernel launch failed */
+  WGNN_ERR_HIP = -6,         /* a HIP runtime call or kernel launch failed */
+  WGNN_ERR_RANGE = -7        /* host bindings raise this when they read a non-zero status word (see Status block) */
 } wgnn_status;
 
 /* math mode of the contractions (I/O is always fp32) */

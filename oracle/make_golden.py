@@ -25,6 +25,7 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, os.path.join(REF, "src"))
 from step6_gcn_gru_combined_model import GCN_GRU  # noqa: E402
 from step2_graph_builder import build_graph  # noqa: E402
+import step4_sequence_preparer as step4  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 F = 13
@@ -91,8 +92,33 @@ def make(name, S, T, B, seed, A64, state_dict=None, H=None):
                                                             os.path.getsize(path) / 1024))
 
 
+def make_windows_fixture(name, Ttot, S, seq, seed):
+    """Row N2: the reference's own window builder (src/step4_sequence_preparer.py:7-27, `__create_sequences`,
+    a module-level function reached through the module dict) on a seeded [time, station, 15-column] array, with
+    np.random seeded so its shuffle (:23-26) is reproducible.  Stored: the input array, the shuffled xs / ys it
+    returned, and the permutation it drew (recovered by re-drawing with the same seed)."""
+    create = step4.__dict__["__create_sequences"]
+    rng = np.random.default_rng(seed)
+    data = rng.random((Ttot, S, 15)).astype(np.float32)
+    np.random.seed(seed)
+    xs, ys = create(data, seq)
+    np.random.seed(seed)
+    perm = np.arange(xs.shape[0])
+    np.random.shuffle(perm)                                   # the same draw as :23-24
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, data=data, xs=xs, ys=ys, perm=perm.astype(np.int32), seq=np.int32(seq))
+    print("%-28s Ttot=%d S=%d seq=%d windows=%d  %.1f KB" % (name, Ttot, S, seq, xs.shape[0],
+                                                              os.path.getsize(path) / 1024))
+
+
 def main():
+    only = set(sys.argv[1:])                                  # optional: regenerate just the named fixtures
     os.makedirs(OUT, exist_ok=True)
+    if only:
+        global make, make_windows_fixture
+        _make, _mw = make, make_windows_fixture
+        make = lambda name, *a, **k: _make(name, *a, **k) if name in only else None                  # noqa: E731
+        make_windows_fixture = lambda name, *a, **k: _mw(name, *a, **k) if name in only else None   # noqa: E731
     A7, A34 = ref_adjacency(7), ref_adjacency(34)
     rng = np.random.default_rng(3)
     A3 = rng.random((3, 3)) * 0.5 + 0.05                      # tiny, deliberately asymmetric
@@ -105,6 +131,13 @@ def main():
     make("f3_s34_t24_b4_ckpt", 34, 24, 4, 31, A34, sd34)
     make("f3b_s34_t24_b4_rand", 34, 24, 4, 32, A34)
     make("f4_s34_t168_b1_ckpt", 34, 168, 1, 41, A34, sd34)
+    # B = 1 at the 7-station shape: the reference's own call shape (src/main.py:64-80), for the drop-in loop test
+    make("f5_s7_t12_b1_rand", 7, 12, 1, 51, A7)
+    # row N2: windows built by the reference's __create_sequences (src/step4_sequence_preparer.py:7-27)
+    make_windows_fixture("w1_t131_s7_seq12", 131, 7, 12, 5)
+    make_windows_fixture("w2_t75_s3_seq24", 75, 3, 24, 6)     # len % seq == 3: the last window's labels just fit
+    if only and "graph_7_34" not in only:
+        return
     # adjacency-only fixtures for the build_graph restatement (row N1)
     np.savez_compressed(os.path.join(OUT, "graph_7_34.npz"), A7=A7, A34=A34,
                         coords34=station_frame(34)[["Latitude", "Longitude"]].values)

@@ -13,7 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 PARAM_KEYS = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias",
               "gru.weight_ih_l0", "gru.weight_hh_l0", "gru.bias_ih_l0", "gru.bias_hh_l0"]
 FIXTURES = ["f1_tiny_s3_t2_b1", "f1b_tiny_s3_t5_b3_h5", "f2_s7_t12_b32_ckpt", "f2b_s7_t12_b4_rand",
-            "f3_s34_t24_b4_ckpt", "f3b_s34_t24_b4_rand", "f4_s34_t168_b1_ckpt"]
+            "f3_s34_t24_b4_ckpt", "f3b_s34_t24_b4_rand", "f4_s34_t168_b1_ckpt", "f5_s7_t12_b1_rand"]
+WINDOW_FIXTURES = ["w1_t131_s7_seq12", "w2_t75_s3_seq24"]   # outputs of the reference's __create_sequences
 
 
 def pytest_configure(config):

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(L.EXPORTS), (declared ^ set(L.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.wgnn_version() == 100
+    assert lib.wgnn_version() == 110
 
 
 def test_dims_validation_no_gpu_needed():
@@ -117,3 +117,35 @@ def test_knn_csr_adjacency_host_logic():
     assert np.abs(DT - D.T.astype(np.float32)).max() == 0.0
     with pytest.raises(ValueError):
         CsrAdjacency([0, 1], [5], [1.0])
+
+
+def test_csr_adjacency_for_another_graph_is_refused_on_the_host():
+    """The kernels find rowptr / col / val inside the CSR buffer from S and nnz; a buffer built for a different
+    station count (or a corrupted one) must never reach them (out-of-bounds device reads otherwise)."""
+    from windgnn_amd.functional import _adj
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    csr = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(20, seed=1), 4))
+    with pytest.raises(RuntimeError, match="does not match 34 stations"):
+        _adj(csr, 34)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # right graph, but still on the host
+        _adj(csr, 20)
+    csr.blob = csr.blob[:-1]
+    with pytest.raises(RuntimeError, match="words"):
+        _adj(csr, 20)
+    csr.blob = torch.zeros(2 * 21 + 4 * csr.nnz, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="int32"):
+        _adj(csr, 20)
+
+
+def test_reference_import_header_resolves_with_the_documented_swap():
+    """src/main.py gets `nn`, `torch`, `np` and GraphConvLayer only through its star
+    imports (src/main.py:4-8; step6 does `import torch.nn as nn`).  With the documented replacement lines every
+    name the loop body uses (src/main.py:41-52,64-108) must still resolve."""
+    ns = {}
+    exec("from windgnn_amd.dropin import *", ns)                      # the documented one-line swap
+    for name in ("GCN_GRU", "GraphConvLayer", "nn", "torch"):
+        assert name in ns, name
+    assert ns["nn"].MSELoss is torch.nn.MSELoss                       # src/main.py:49
+    m = ns["GCN_GRU"](input_dim=13, hidden_dim=13, output_dim=13, gru_input=7 * 13, gru_hidden_dim=21)
+    assert list(m.state_dict().keys()) == PARAM_KEYS
+    assert callable(ns["torch"].optim.Adam)                           # src/main.py:52

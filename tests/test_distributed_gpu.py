@@ -23,29 +23,40 @@ def _free_port():
     return p
 
 
-def _train(rank, world, port, out_dir):
+def _train(rank, world, port, out_dir, backend="gloo", tag=None):
     from windgnn_amd import GCN_GRU
     from windgnn_amd.distributed import shard_windows
     from windgnn_amd.trainer import TrainStep
-    if world > 1:
+    group = None
+    if world > 1 or backend == "nccl":
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+            group = dist.group.WORLD            # an explicit group: TrainStep runs its collective path even with 1 rank
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     fx = load_fixture("f2_s7_t12_b32_ckpt")
     m = GCN_GRU(13, 13, 13, 7 * 13, 21, math="f16x3")
     m.load_state_dict({k: v.clone() for k, v in fx["params"].items()})
     m = m.to(dev)
-    tr = TrainStep(m)
+    tr = TrainStep(m, process_group=group)
+    assert tr.collective == (world > 1 or backend == "nccl")
     A = torch.from_numpy(fx["A"]).to(dev)
     X, L = torch.from_numpy(fx["X"]), torch.from_numpy(fx["L"])
     Xs, Ls = shard_windows(X, L, rank, world)
     Xs, Ls = Xs.contiguous().to(dev), Ls.contiguous().to(dev)
+    losses = []
     for _ in range(2):
-        tr.step(A, Xs, Ls)
+        loss, _ = tr.step(A, Xs, Ls)
+        losses.append(float(loss))
     torch.cuda.synchronize()
     if rank == 0:
-        np.save(os.path.join(out_dir, "p_world%d.npy" % world), tr.flat_p.cpu().numpy())
-    if world > 1:
+        np.save(os.path.join(out_dir, "p_%s.npy" % (tag or "world%d" % world)), tr.flat_p.cpu().numpy())
+        np.save(os.path.join(out_dir, "loss_%s.npy" % (tag or "world%d" % world)), np.array(losses))
+    if world > 1 or backend == "nccl":
         dist.barrier()
         dist.destroy_process_group()
 
@@ -58,3 +69,23 @@ def test_two_rank_training_equals_single_process(tmp_path):
     p2 = torch.from_numpy(np.load(os.path.join(str(tmp_path), "p_world2.npy")))
     # Adam moves each weight by ~1e-3 per step; shard-sum vs big-batch gradients differ only by fp32 rounding
     assert max_abs(p1, p2) <= 2e-5
+
+    # the loss every rank returns is the big-batch mean loss, not its shard's
+    l1 = np.load(os.path.join(str(tmp_path), "loss_world1.npy"))
+    l2 = np.load(os.path.join(str(tmp_path), "loss_world2.npy"))
+    assert np.abs(l1 - l2).max() <= 1e-6 * max(1.0, float(np.abs(l1).max()))
+
+
+def test_rccl_allreduce_path_executes_and_is_bitwise_neutral_with_one_rank(tmp_path):
+    """The RCCL ("nccl") code path of TrainStep.step -- init_process_group("nccl"), the async all-reduce of the GRU
+    gradients overlapped with backward part 2, the conv-gradient + loss all-reduce -- executed for real in a fresh
+    child process on the one GPU this box has (world_size 1: RCCL refuses two ranks on one device).  A one-rank sum
+    is the identity, so the parameters after two steps must equal the no-group run bit for bit."""
+    assert torch.cuda.is_available()
+    mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "gloo", "plain"), nprocs=1, join=True)
+    mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1"), nprocs=1, join=True)
+    p0 = np.load(os.path.join(str(tmp_path), "p_plain.npy"))
+    p1 = np.load(os.path.join(str(tmp_path), "p_rccl1.npy"))
+    assert np.array_equal(p0, p1)
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "loss_plain.npy")),
+                          np.load(os.path.join(str(tmp_path), "loss_rccl1.npy")))

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import PARAM_KEYS, load_fixture, max_abs, rel_to_max
+from conftest import PARAM_KEYS, WINDOW_FIXTURES, load_fixture, max_abs, rel_to_max
 
 pytestmark = pytest.mark.gpu
 
@@ -176,25 +176,30 @@ def test_f16x3_tiny_gradients_survive_range_scaling():
         assert rel_to_max(v.grad.cpu(), go[k]) <= G_TOL, k
 
 
-def test_make_windows_bit_exact_vs_oracle():
-    """N2: on-device window batcher == src/step4_sequence_preparer.py:7-21 (oracle.make_windows), bit for bit."""
-    import numpy as np
+@pytest.mark.parametrize("name", WINDOW_FIXTURES)
+def test_make_windows_bit_exact_vs_reference_fixture(name):
+    """N2: the on-device window batcher against what the reference's own __create_sequences returned
+    (src/step4_sequence_preparer.py:7-27; fixture made by oracle/make_golden.py with np.random seeded), bit for bit:
+    default call = the un-shuffled windows, `starts` = the reference's shuffled order."""
+    import os
+    from conftest import GOLDEN
     from oracle import windgnn_oracle as orc
     from windgnn_amd.data import make_windows
     dev = _dev()
-    rng = np.random.default_rng(5)
-    Ttot, S, seq = 131, 7, 12
-    data = rng.random((Ttot, S, 15)).astype(np.float32)          # 2 id columns + 13 features, as the reference
-    xs, ys = orc.make_windows(data[: (Ttot - 3) // seq * seq + 3], seq)
-    feat = torch.from_numpy(np.ascontiguousarray(data[:, :, 2:15])).to(dev)
-    X, L = make_windows(feat, seq)
-    assert X.shape == xs.shape and L.shape == ys.shape
-    assert torch.equal(X.cpu(), torch.from_numpy(xs)) and torch.equal(L.cpu(), torch.from_numpy(ys))
-    perm = [3, 0, 7, 5]                                            # shuffled windows (:23-26)
-    Xp, Lp = make_windows(feat, seq, starts=[p * seq for p in perm])
-    assert torch.equal(Xp.cpu(), torch.from_numpy(xs[perm])) and torch.equal(Lp.cpu(), torch.from_numpy(ys[perm]))
-    with pytest.raises(RuntimeError):                              # a window whose labels run past the data
-        make_windows(feat, seq, starts=[Ttot - seq - 2])
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    data, seq, perm = z["data"], int(z["seq"]), z["perm"]
+    feat = torch.from_numpy(np.ascontiguousarray(data[:, :, 2:15])).to(dev)   # the 13 feature columns (:14)
+    Xs, Ls = make_windows(feat, seq, starts=[int(p) * seq for p in perm])     # the reference's shuffled order (:23-26)
+    assert torch.equal(Xs.cpu(), torch.from_numpy(z["xs"])) and torch.equal(Ls.cpu(), torch.from_numpy(z["ys"]))
+    X, L = make_windows(feat, seq)                                            # default: windows i * seq, reference count
+    assert X.shape[0] == len(perm)
+    assert torch.equal(X.cpu()[perm], torch.from_numpy(z["xs"])) and torch.equal(L.cpu()[perm], torch.from_numpy(z["ys"]))
+    xo, yo = orc.make_windows(data, seq)                                      # and the oracle agrees (pinned on CPU too)
+    assert torch.equal(X.cpu(), torch.from_numpy(xo)) and torch.equal(L.cpu(), torch.from_numpy(yo))
+    with pytest.raises(RuntimeError):                                         # a window whose labels run past the data
+        make_windows(feat, seq, starts=[data.shape[0] - seq - 2])
+    with pytest.raises(RuntimeError):                                         # len % seq < 3: the reference's concatenate fails
+        make_windows(feat[: seq * 2 + 1], seq)
 
 
 def test_predict_last_matches_reference_readout():
@@ -211,24 +216,27 @@ def test_predict_last_matches_reference_readout():
     assert max_abs(out, ref) <= 1e-4 * (wmax - wmin)
 
 
-def test_full_size_properties_B4096():
-    """BASELINE's full size (S=34, T=24, B=4096, H=102, f16x3): properties that need no oracle run.
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+def test_full_size_properties_B4096(math):
+    """BASELINE's full size (S=34, T=24, B=4096, H=102) in the fp32-grade mode (f16x3, configs[3]'s per-GPU shard)
+    and in the 16-bit mode (f16, configs[2]): properties that need no oracle run, plus an oracle-checked slice.
     (a) windows are independent: the big batch equals its two halves run separately, bit for bit;
     (b) the backward is linear in dY and the range scaling is a power of two: grads(4*dY) == 4*grads(dY) exactly;
     (c) gradients add over windows: grads(batch) ~= grads(half 1) + grads(half 2);
-    (d) a 256-window slice agrees with the fp64 oracle."""
+    (d) a 256-window slice agrees with the fp64 oracle (Y and all 8 gradients) at the mode's stated tolerance."""
     from oracle import windgnn_oracle as orc
     from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
     import numpy as np, os
     from conftest import GOLDEN
     dev = _dev()
+    y_tol, g_tol = (Y_TOL, G_TOL) if math == "f16x3" else (F16_Y_TOL, F16_G_TOL)
     S, T, B, H = 34, 24, 4096, 102
     A = torch.from_numpy(np.load(os.path.join(GOLDEN, "graph_7_34.npz"))["A34"]).float()
     g = torch.Generator().manual_seed(99)
     X = torch.rand(B, T, S, 13, generator=g)
     dY = (torch.rand(B, T, H, generator=g) - 0.5) * 1e-6
     p = orc.init_params(S, 13, H, seed=3)
-    model = _model_from(p, S, H, "f16x3")
+    model = _model_from(p, S, H, math)
     params = [q.detach() for q in model.hot_path_parameters()]
     Ad, Xd, dYd = A.to(dev), X.to(dev), dY.to(dev)
 
@@ -248,8 +256,17 @@ def test_full_size_properties_B4096():
     for a, b, c in zip(G, G1, G2):
         assert rel_to_max((b + c).cpu(), a.cpu()) <= 1e-5                                      # (c)
     n = 256
-    Yo, cache = orc.forward(A.double(), X[:n].double(), {k: v.double() for k, v in p.items()})
-    assert max_abs(Y[:n].cpu(), Yo) <= Y_TOL                                                   # (d)
+    p64 = {k: v.double() for k, v in p.items()}
+    Yo, cache = orc.forward(A.double(), X[:n].double(), p64)
+    go = orc.backward(A.double(), X[:n].double(), p64, Yo, cache, dY[:n].double())
+    Yn, Gn = run(Xd[:n].contiguous(), dYd[:n].contiguous())
+    assert torch.equal(Yn, Y[:n])
+    ey = max_abs(Yn.cpu(), Yo)
+    assert ey <= y_tol, ey                                                                    # (d)
+    if math == "f16":
+        assert ey > 1e-6                       # this really is the one-pass 16-bit path
+    for k, gk in zip(PARAM_KEYS, Gn):
+        assert rel_to_max(gk.cpu(), go[k]) <= g_tol, k
 
 
 def test_backward_in_two_parts_equals_one_call():
@@ -460,3 +477,206 @@ def test_graph_conv_layer_with_csr_adjacency():
     assert rel_to_max(Xd.grad.cpu(), gX) <= 1e-5
     assert rel_to_max(layer_d.weight.grad.cpu(), gW) <= 1e-5
     assert rel_to_max(layer_d.bias.grad.cpu(), gb) <= 1e-5
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("fixture", ["f5_s7_t12_b1_rand", "f1_tiny_s3_t2_b1", "f4_s34_t168_b1_ckpt"])
+def test_reference_training_loop_body_verbatim_through_the_dropin(fixture, math, tmp_path):
+    """src/main.py:41-52,64-99 with ONLY the import swapped: torch's own nn.MSELoss (with the reference's
+    [T,H] vs [1,T,H] broadcast), loss.backward(), torch.optim.Adam, torch.save(state_dict) -> a fresh model ->
+    load_state_dict(torch.load).  Parameters after 1 and 3 optimiser steps against the reference's own
+    trajectories (a1.* / a3.* of the B = 1 fixtures, written by oracle/make_golden.py running the reference)."""
+    import warnings
+    import torch.nn as nn
+    from windgnn_amd import GCN_GRU
+    device = _dev()
+    fx = load_fixture(fixture)
+    num_stations = fx["A"].shape[0]
+    num_attr = 13
+    attr_station_flat = num_attr * num_stations
+    num_predictions = fx["Y"].shape[-1]
+    adj_matrix = torch.tensor(fx["A64"]).float().to(device)                                   # :25-27
+    model = GCN_GRU(input_dim=num_attr, hidden_dim=num_attr, output_dim=num_attr, gru_input=attr_station_flat,
+                    gru_hidden_dim=num_predictions, math=math)                                # :41-42 (+ math)
+    model.load_state_dict({k: v.clone() for k, v in fx["params"].items()})                   # same start as the fixture
+    model = model.to(device)                                                                  # :43
+    lossFunction = nn.MSELoss()                                                               # :49
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.001)                                # :52
+    batch_x, batch_y = torch.from_numpy(fx["X"]).to(device), torch.from_numpy(fx["L"]).to(device)   # [1,T,S,13], [1,T,3S]
+    PATH = str(tmp_path / "wind_gnn.pth")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                                       # the broadcast warning of :72
+        for it in (1, 2, 3):
+            outputs = model(adj_matrix, batch_x)                                              # :66
+            optimizer.zero_grad()                                                             # :69
+            loss = lossFunction(outputs, batch_y)                                             # :72
+            loss.backward()                                                                   # :79
+            optimizer.step()                                                                  # :80
+            if it == 1:
+                assert tuple(outputs.shape) == (batch_x.shape[1], num_predictions)            # squeeze(0), step6:26
+                assert abs(loss.item() - float(fx["loss"])) <= 1e-5
+            if it in (1, 3):
+                torch.save(model.state_dict(), PATH)                                          # :84
+                fresh = GCN_GRU(input_dim=num_attr, hidden_dim=num_attr, output_dim=num_attr,
+                                gru_input=attr_station_flat, gru_hidden_dim=num_predictions)  # :96-98
+                fresh = fresh.to(device)
+                fresh.load_state_dict(torch.load(PATH))                                       # :99
+                for k, v in fresh.state_dict().items():
+                    assert max_abs(v.cpu(), fx["a%d.%s" % (it, k)]) <= 2e-5, (it, k)
+    with torch.no_grad():                                                                     # :100-102
+        out = fresh(adj_matrix, batch_x)
+    assert tuple(out.shape) == (batch_x.shape[1], num_predictions) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f32"])
+def test_4096_station_config_at_full_width_H12288_against_host_fp64(math):
+    """BASELINE configs[4] at its REAL width (S = 4096 stations in CSR, I = 53 248, H = 12 288, G = 36 864) with a
+    small B*T (B = 2, T = 2) so that a host fp64 evaluation of the same formulas stays affordable: exercises the
+    46-per-step split-K W_hh plane GEMMs' code path (here 1 per direction), the 27/18-chunk K summation at N = 36 864
+    and the 9.7 GB weight re-split, none of which the H = 24 test reaches.  Checked: ALL of Y, db_ih, db_hh and the
+    four conv gradients, and 96 complete rows each of dW_ih and dW_hh, against fp64 dot products on the host; plus
+    window independence and dY-linearity at this width."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd import _lib
+    from windgnn_amd.functional import gcn_gru_backward_mse_raw, gcn_gru_forward_raw
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    dev = _dev()
+    S, T, B, H, F = 4096, 2, 2, 12288, 13
+    I, G3 = S * F, 3 * H
+    csr = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=7), 8))
+    A64 = csr.dense().double()
+    gen = torch.Generator().manual_seed(12288)
+    X = torch.rand(B, T, S, F, generator=gen)
+    L = torch.rand(B, T, H, generator=gen)
+    k = 1.0 / H ** 0.5                                          # nn.GRU's U(+-1/sqrt(hidden)) at the real width
+    gd = torch.Generator(device=dev).manual_seed(7)
+    small = {"conv1.weight": torch.randn(F, F, generator=gen), "conv1.bias": torch.rand(F, generator=gen) * 0.1,
+             "conv2.weight": torch.randn(F, F, generator=gen), "conv2.bias": torch.rand(F, generator=gen) * 0.1}
+    w_ih = (torch.rand(G3, I, device=dev, generator=gd) * 2 - 1) * k
+    w_hh = (torch.rand(G3, H, device=dev, generator=gd) * 2 - 1) * k
+    b_ih = (torch.rand(G3, device=dev, generator=gd) * 2 - 1) * k
+    b_hh = (torch.rand(G3, device=dev, generator=gd) * 2 - 1) * k
+    params = [small[n].to(dev) for n in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias")] + [w_ih, w_hh, b_ih, b_hh]
+    mode = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3}[math]
+    csr_d = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=7), 8)).to(dev)
+    Xd, Ld = X.to(dev), L.to(dev)
+
+    def run(Xs, Ls, scale=1.0):
+        Y, stash, d = gcn_gru_forward_raw(csr_d, Xs, params, mode, want_stash=True)
+        grads = [torch.empty_like(q) for q in params]
+        loss = torch.empty((), device=dev)
+        gcn_gru_backward_mse_raw(d, csr_d, Xs, params, Y, Ls, stash, grads, loss, scale)
+        return Y, grads, loss
+
+    Y, G, loss = run(Xd, Ld)
+    torch.cuda.synchronize()
+
+    # ---- host fp64 evaluation of the same formulas (oracle GCN layers; GRU by chunked dot products)
+    p64 = {n: v.double() for n, v in small.items()}
+    g64, cache = orc.gcn2_forward(A64, X.double(), p64)         # [B,T,I]
+    g2 = g64.reshape(B * T, I)
+    CH = 3072
+    GI = torch.empty(B * T, G3, dtype=torch.float64)
+    for r0 in range(0, G3, CH):                                 # GI = g W_ih^T + b_ih, 12 chunks of W_ih rows
+        W = w_ih[r0:r0 + CH].cpu().double()
+        GI[:, r0:r0 + CH] = g2 @ W.t()
+    GI += b_ih.cpu().double()
+    GI = GI.reshape(B, T, G3)
+    whh64 = w_hh.cpu().double()                                 # 3.6 GB as fp64
+    bhh64 = b_hh.cpu().double()
+
+    def cell(gi, hprev):
+        gh = hprev @ whh64.t() + bhh64
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        return (1 - z) * n + z * hprev, r, z, n, gh[:, 2 * H:]
+
+    h0 = torch.zeros(B, H, dtype=torch.float64)
+    h1, r0_, z0_, n0_, ghn0 = cell(GI[:, 0], h0)
+    h2, r1_, z1_, n1_, ghn1 = cell(GI[:, 1], h1)
+    Yo = torch.stack([h1, h2], dim=1)
+    assert max_abs(Y.cpu(), Yo) <= Y_TOL
+    lo = ((Yo - L.double()) ** 2).mean()
+    assert abs(float(loss) - float(lo)) <= 1e-5 * max(1.0, float(lo))
+    dYo = 2.0 * (Yo - L.double()) / Yo.numel()
+
+    def cell_bwd(dh, hprev, r, z, n, ghn):
+        dn = dh * (1 - z); dz = dh * (hprev - n); dnt = dn * (1 - n * n); dr = dnt * ghn
+        dar = dr * r * (1 - r); daz = dz * z * (1 - z)
+        dgi = torch.cat([dar, daz, dnt], dim=1); dgh = torch.cat([dar, daz, dnt * r], dim=1)
+        return dgi, dgh, dh * z + dgh @ whh64
+
+    dgi1, dgh1, dhp = cell_bwd(dYo[:, 1], h1, r1_, z1_, n1_, ghn1)
+    dgi0, dgh0, _ = cell_bwd(dYo[:, 0] + dhp, h0, r0_, z0_, n0_, ghn0)
+    dGI = torch.stack([dgi0, dgi1], dim=1).reshape(B * T, G3)
+    dGH = torch.stack([dgh0, dgh1], dim=1).reshape(B * T, G3)
+    Hprev = torch.stack([h0, h1], dim=1).reshape(B * T, H)
+    assert rel_to_max(G[6].cpu(), dGI.sum(0)) <= G_TOL          # db_ih, all 36 864 entries
+    assert rel_to_max(G[7].cpu(), dGH.sum(0)) <= G_TOL          # db_hh
+    rows = torch.cat([torch.randint(q * H, (q + 1) * H, (32,), generator=gen) for q in range(3)])   # 32 rows per gate
+    dWih_max = float(G[4].abs().max())                          # tensor max taken from the device result (checked rows dominate)
+    ref_ih = dGI[:, rows].t() @ g2                              # [96, I]
+    assert max_abs(G[4][rows.to(dev)].cpu(), ref_ih) <= G_TOL * max(dWih_max, float(ref_ih.abs().max()))
+    ref_hh = dGH[:, rows].t() @ Hprev
+    dWhh_max = float(G[5].abs().max())
+    assert max_abs(G[5][rows.to(dev)].cpu(), ref_hh) <= G_TOL * max(dWhh_max, float(ref_hh.abs().max()))
+    dg = torch.zeros(B * T, I, dtype=torch.float64)
+    for r0 in range(0, G3, CH):                                 # dg = dGI W_ih, chunked over the gate rows
+        dg += dGI[:, r0:r0 + CH] @ w_ih[r0:r0 + CH].cpu().double()
+    gconv = orc.gcn2_backward(A64, p64, cache, dg.reshape(B, T, S, F))
+    for i, n in enumerate(("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias")):
+        assert rel_to_max(G[i].cpu(), gconv[n]) <= G_TOL, n
+    del whh64
+
+    # ---- properties at this width: windows independent; gradients linear in the loss scale (exact: power-of-two)
+    Ya, Ga, _ = run(Xd[:1].contiguous(), Ld[:1].contiguous(), 0.5)     # window 0 alone = half of the batch mean
+    Yb, Gb, _ = run(Xd[1:].contiguous(), Ld[1:].contiguous(), 0.5)
+    assert max_abs(Ya.cpu(), Y[:1].cpu()) <= 1e-6 and max_abs(Yb.cpu(), Y[1:].cpu()) <= 1e-6
+    for a, b, c in zip(G, Ga, Gb):
+        assert rel_to_max((b + c).cpu(), a.cpu()) <= 2e-5
+    _, G4, _ = run(Xd, Ld, 4.0)
+    for a, b in zip(G, G4):
+        assert torch.equal(a * 4.0, b)
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+def test_fp16_plane_modes_report_out_of_range_values_loudly(math):
+    """The reference's fp32 path has no range limit; the fp16-plane modes do (|x| < 65520).  Un-normalised inputs
+    (X * 1e4) with large conv weights (* 1e3), or GRU weights beyond fp16's range, must raise -- never return
+    inf/NaN-derived numbers or, behind the ReLU, a silent 0 -- and math='f32' must still match the fp64 oracle."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.functional import check_range_status
+    from windgnn_amd.trainer import TrainStep
+    dev = _dev()
+    fx = load_fixture("f3b_s34_t24_b4_rand")
+    A, X, L = (torch.from_numpy(fx[k]) for k in ("A", "X", "L"))
+    p = {k: v.clone() for k, v in fx["params"].items()}
+    p["conv1.weight"] *= 1e3
+    p["conv2.weight"] *= 1e3
+    Xbig = X * 1e4
+    check_range_status(dev)                                      # nothing pending from earlier tests
+    model = _model_from(p, 34, 102, math)
+    with pytest.raises(RuntimeError, match="fp16's range"):
+        model(A.to(dev), Xbig.to(dev))
+    check_range_status(dev)                                      # the report was consumed
+    out = _model_from(fx["params"], 34, 102, math)(A.to(dev), X.to(dev))      # normal inputs: no report
+    assert bool(torch.isfinite(out).all())
+    p2 = {k: v.clone() for k, v in fx["params"].items()}
+    p2["gru.weight_ih_l0"][5, 7] = 1e6                           # one weight beyond fp16's range
+    with pytest.raises(RuntimeError, match="weight"):
+        _model_from(p2, 34, 102, math)(A.to(dev), X.to(dev))
+    p3 = {k: v.clone() for k, v in fx["params"].items()}
+    p3["gru.weight_hh_l0"][3, 2] = -7e4
+    with pytest.raises(RuntimeError, match="weight"):
+        _model_from(p3, 34, 102, math)(A.to(dev), X.to(dev))
+    # the training loop body (no per-step synchronisation): the periodic check raises
+    tr = TrainStep(_model_from(p, 34, 102, math), check_every=2)
+    with pytest.raises(RuntimeError, match="fp16's range"):
+        for _ in range(2):
+            tr.step(A.to(dev), Xbig.to(dev), L.to(dev))
+    # exact fp32 mode: same inputs, no limit, still the reference's numbers
+    Yo, _ = orc.forward(A.double(), Xbig.double(), {k: v.double() for k, v in p.items()}, want_cache=False)
+    out32 = _model_from(p, 34, 102, "f32")(A.to(dev), Xbig.to(dev))
+    assert max_abs(out32.detach().cpu().reshape(Yo.shape), Yo) <= Y_TOL
+    check_range_status(dev)

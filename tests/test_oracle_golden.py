@@ -1,9 +1,12 @@
 """Pin the CPU oracle to the reference: every golden fixture (produced by the reference itself,
 oracle/make_golden.py) must be reproduced by the restatement in oracle/windgnn_oracle.py."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
-from conftest import PARAM_KEYS, load_fixture, max_abs, rel_to_max
+from conftest import GOLDEN, PARAM_KEYS, WINDOW_FIXTURES, load_fixture, max_abs, rel_to_max
 from oracle import windgnn_oracle as orc
 
 
@@ -61,3 +64,14 @@ def test_build_graph_matches_reference():
     assert np.abs(A34 - z["A34"]).max() <= 1e-12
     A7 = orc.build_graph(z["coords34"][:7])
     assert np.abs(A7 - z["A7"]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("name", WINDOW_FIXTURES)
+def test_make_windows_matches_reference_create_sequences(name):
+    """Row N2 pin: oracle.make_windows (no shuffle) + the stored permutation == what the reference's
+    __create_sequences returned for the same array (src/step4_sequence_preparer.py:7-27), bit for bit."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    xs, ys = orc.make_windows(z["data"], int(z["seq"]))
+    assert xs.shape == z["xs"].shape and ys.shape == z["ys"].shape
+    assert np.array_equal(xs[z["perm"]], z["xs"]) and np.array_equal(ys[z["perm"]], z["ys"])
+    assert sorted(z["perm"].tolist()) == list(range(xs.shape[0]))

@@ -15,6 +15,7 @@ MATH_F16X3 = 1
 MATH_F16 = 2
 ADJ_DENSE = 0
 ADJ_CSR = 1
+STATUS_BYTES = 256          # WGNN_STATUS_BYTES: status block at the start of every workspace
 
 
 class Dims(C.Structure):
@@ -87,7 +88,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.wgnn_version() < 100:
+    if lib.wgnn_version() < 110:
         raise RuntimeError("windgnn_amd: libwindgnn_hip.so is too old")
     _lib = lib
     return lib

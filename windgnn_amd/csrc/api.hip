@@ -51,7 +51,8 @@ Layout make_layout(const wgnn_dims* d) {
   auto al = [](size_t x) { return align_up(x, 64); };
   const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : 0;   // 2 planes of halfs = that many floats
   const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : 0;
-  size_t o = 0;
+  constexpr size_t HDR = WGNN_STATUS_BYTES / sizeof(float);   // status block at the start of the workspace
+  size_t o = HDR;
   L.ws_GI = o; o += al(L.BT * L.Gp);   // rows padded to 128-B multiples
   L.ws_g = o; o += al(L.BT * L.Ip);    // fp32 g (f32 mode) or its two fp16 planes (f16x3): same bytes
   L.ws_planes_f = o; o += al(planes_f);
@@ -82,7 +83,7 @@ Layout make_layout(const wgnn_dims* d) {
     part_ih = pgemm_tn_partial_floats((int)L.G3, (int)L.I + 1, L.sk_ih);
     part_hh = pgemm_tn_partial_floats((int)L.G3, (int)L.H + 1, L.sk_hh);
   }
-  o = 0;
+  o = HDR;
   L.ws_dGI = o; o += al(L.BT * L.Gp);   // fp32, or hi+lo fp16 planes (same bytes)
   L.ws_dGH = o; o += al(L.BT * L.Gp);
   L.ws_dg = o; o += al(L.BT * L.I);
@@ -141,6 +142,9 @@ const char* wgnn_strerror(int status) {
     case WGNN_ERR_UNSUPPORTED:
       return "configuration not supported by this build (a dense adjacency needs S <= 64: pass larger graphs as CSR)";
     case WGNN_ERR_HIP: return "HIP runtime error (kernel launch failed)";
+    case WGNN_ERR_RANGE:
+      return "a value left fp16's range in an fp16-plane math mode (status block bits: 1 activation, 2 weight, 4 "
+             "non-finite gradient): normalise the inputs or use WGNN_MATH_F32";
     default: return "unknown status";
   }
 }
@@ -168,6 +172,7 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   if (workspace_bytes < sizeof(float) * L.fwd_floats) return WGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
+  unsigned* status = (unsigned*)workspace;           // word 0 of the status block (include/windgnn.h)
   float* sf = (float*)stash;
   float* GI = ws + L.ws_GI;
   float* g = sf ? sf + L.st_g : ws + L.ws_g;
@@ -178,14 +183,14 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   if (x3) {
     // W_ih as stage-major fp16 planes [np_g3][Ip] with b_ih folded into column I (g's ones column)
     rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, (int)L.I, ws + L.ws_planes_f, L.np_g3,
-                              (int)L.Ip, st);
+                              (int)L.Ip, status, st);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gcn)    // CSR adjacency: fp32 SpMM layers, layer 2 writes the g planes
       rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight,
-                               p->conv2_bias, sf ? sf + L.st_h1 : ws + L.ws_h1, nullptr, g, L.Ip, full, st);
+                               p->conv2_bias, sf ? sf + L.st_h1 : ws + L.ws_h1, nullptr, g, L.Ip, full, status, st);
     else
       rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                            (int)L.Ip, full, st);
+                            (int)L.Ip, full, status, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
@@ -193,19 +198,19 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     if (rc != WGNN_OK) return rc;
     if (L.gen_gru) {  // any hidden width: one plane GEMM per step against split(W_hh | b_hh)
       rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 0, p->b_hh, (int)L.H, ws + L.ws_hhp_f, L.np_g3, (int)L.Hp,
-                                st);
+                                status, st);
       if (rc != WGNN_OK) return rc;
       return launch_gru_gen_fwd_x3(d->B, d->T, d->H, GI, (int)L.Gp, ws + L.ws_hhp_f, L.np_g3, p->b_hh, Y, gates,
                                    sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, ws + L.ws_kp_f, ws + L.ws_hc, full,
                                    st);
     }
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
-                           full, st);
+                           full, status, st);
   }
   if (L.gen_gcn) {
     float* h1 = sf ? sf + L.st_h1 : ws + L.ws_h1;    // layer-1 activations: kept for the backward if there is a stash
     rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight,
-                             p->conv2_bias, h1, g, nullptr, L.Ip, false, st);
+                             p->conv2_bias, h1, g, nullptr, L.Ip, false, nullptr, st);
   } else {
     rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
                          (int)L.Ip, st);
@@ -250,6 +255,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   if (workspace_bytes < sizeof(float) * L.bwd_floats) return WGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
+  unsigned* status = (unsigned*)workspace;
   const float* sf = (const float*)stash;
   const float* gact = sf + L.st_g;
   const float* gates = sf + L.st_gates;
@@ -282,7 +288,8 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
         rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the scales
       if (rc != WGNN_OK) return rc;
       if (L.gen_gru) {
-        rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 1, nullptr, 0, ws + L.ws_hhp_b, L.np_h, (int)L.Gp, st);
+        rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 1, nullptr, 0, ws + L.ws_hhp_b, L.np_h, (int)L.Gp, status,
+                                  st);
         if (rc != WGNN_OK) return rc;
         rc = launch_gru_gen_bwd_x3(d->B, d->T, d->H, ws + L.ws_hhp_b, L.np_h, Y, dY, gates, scales, dGIh, dGHh,
                                    (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, ws + L.ws_kp_b, ws + L.ws_dc, full, st);
@@ -298,19 +305,20 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
                            L.sk_hh, part, (int)L.G3, (int)L.H + 1, full, st);
       if (rc != WGNN_OK) return rc;
       rc = launch_pgemm_tn_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
-                                  st);
+                                  status, st);
       if (rc != WGNN_OK) return rc;
       // dW_ih | db_ih = dGI^T [g | 1]
       rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part,
                            (int)L.G3, (int)L.I + 1, full, st);
       if (rc != WGNN_OK) return rc;
       rc = launch_pgemm_tn_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales,
-                                  st);
+                                  status, st);
       if (rc != WGNN_OK) return rc;
     }   // the four GRU gradients are final here: a data-parallel caller can start reducing them now
     if (!do_gcn) return WGNN_OK;
     // dg = dGI W_ih   (B operand = split(W_ih^T) [np_i][Gp]); dg stays in scaled units
-    rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, ws + L.ws_planes_b, L.np_i, (int)L.Gp, st);
+    rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, ws + L.ws_planes_b, L.np_i, (int)L.Gp, status,
+                              st);
     if (rc != WGNN_OK) return rc;
     rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I,
                          (int)L.I, nullptr, full, nullptr, st);
@@ -323,7 +331,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
                           scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, st);
     if (rc != WGNN_OK) return rc;
     return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT, d->S), g->conv1_weight, g->conv1_bias,
-                                     g->conv2_weight, g->conv2_bias, st);
+                                     g->conv2_weight, g->conv2_bias, status, st);
   }
 
   if (do_rec) {

@@ -71,6 +71,16 @@ extern bool g_prof_on;
     if (g_prof_on) prof_end(st);                  \
   } while (0)
 
+// ---- range status (include/windgnn.h "Status block"): word 0 of the caller's workspace, only ever OR-ed into.
+// The fp16-plane modes cannot represent |x| >= 65520; where a kernel converts activations, weights or final
+// gradients it tests them (one v_cmp per value, NaN counts as out of range) and reports instead of letting an
+// inf/NaN slide through a ReLU (fmaxf(NaN, 0) = 0 would hide it).
+#define WGNN_FP16_MAX 65504.0f
+__device__ __forceinline__ bool out_of_fp16_range(float v) { return !(__builtin_fabsf(v) <= WGNN_FP16_MAX); }
+__device__ __forceinline__ void report_status(unsigned* status, bool bad, unsigned bit) {
+  if (status && bad) atomicOr(status, bit);   // call once per thread, after the loop (error path only)
+}
+
 // ---- internal launchers (defined in the .hip files, used by api.hip) -------------------------
 struct GemmArgs {
   const float* A; int lda; int a_kcontig;   // A(m,k) = a_kcontig ? A[m*lda+k] : A[k*lda+m]
@@ -96,7 +106,7 @@ int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                    float* gates, void* y_planes, bool x3, hipStream_t st);
+                    float* gates, void* y_planes, bool x3, unsigned* status, hipStream_t st);
 // exactly one of dY / labels is non-null (labels: dY = (Y - labels) * scales[2], see launch_mse_stats)
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
                     const float* gates,
@@ -110,24 +120,24 @@ int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const flo
                     const float* b1, const float* W2, const float* g, int ldg, const float* dg, float* dW1,
                     float* db1, float* dW2, float* db2, float* partial, hipStream_t st);
 int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
-                              hipStream_t st);
+                              unsigned* status, hipStream_t st);
 // register-chained split-fp16 variants (gcnx.hip)
 size_t gcnx2_bwd_partial_floats(int ntiles);
 int gcnx_bwd_grid(int ntiles, int S);
 // g_planes: fp16 hi plane [ntiles][ldg] followed by the lo plane; column S*13 holds 1.0, later columns 0
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, hipStream_t st);
+                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, hipStream_t st);
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
                      int scale_in, float* partial, bool x3, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
-                         int Rp, int Cp, hipStream_t st);
+                         int Rp, int Cp, unsigned* status, hipStream_t st);
 int pgemm_nt_np(int N);
 int pgemm_tn_tiles(int Mout, int Nout);   // output tiles per K chunk (sizes the split-K factor)
 size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk);
 int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
-                           float* bias_out, const float* scales, hipStream_t st);
+                           float* bias_out, const float* scales, unsigned* status, hipStream_t st);
 // kpart (nullable): pgemm_nt_kpart_floats(M, ldc, Kp) floats of split-K scratch for few-row, long-K products
 size_t pgemm_nt_kpart_floats(int M, int ldc, int Kp);
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
@@ -138,7 +148,7 @@ int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, 
 size_t gcn_csr_bwd_partial_floats();
 int launch_gcn2_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W1, const float* b1,
                         const float* W2, const float* b2, float* h1, float* g, void* g_planes, size_t ldg, bool x3,
-                        hipStream_t st);
+                        unsigned* status, hipStream_t st);
 int launch_gcn2_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W2, const float* h1,
                         const float* g, const void* g_hi, size_t ldg, const float* dg, size_t ld_dg,
                         const float* scales, float* du, float* partial, float* dW1, float* db1, float* dW2, float* db2,

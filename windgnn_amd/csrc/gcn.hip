@@ -312,7 +312,8 @@ __global__ void __launch_bounds__(256) gcn_bwd_kernel(int ntiles, int S, int F, 
 // sum partial rows (fixed order => bitwise reproducible) and scatter into the [F,F]/[F] gradients.
 // One block per 32 columns; 32 row-groups per block (1024 threads) keep many independent loads in flight.
 __global__ void __launch_bounds__(1024) gcn_partial_reduce_kernel(const float* __restrict__ partial, int nblk, int F,
-                                                                  float* dW1, float* db1, float* dW2, float* db2) {
+                                                                  float* dW1, float* db1, float* dW2, float* db2,
+                                                                  unsigned* status) {
   __shared__ float sm[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + tx;
@@ -333,6 +334,7 @@ __global__ void __launch_bounds__(1024) gcn_partial_reduce_kernel(const float* _
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < 32; ++k) s += sm[k][tx];
+  report_status(status, !(__builtin_fabsf(s) <= 3.0e38f), WGNN_STATUS_GRAD_NONFINITE);
   if (i < FP * FP) {
     int r = i / FP, c = i % FP;
     if (dW1 && r < F && c < F) dW1[r * F + c] = s;
@@ -361,10 +363,10 @@ size_t smem_bytes(int S) {
 }  // namespace
 
 int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
-                              hipStream_t st) {
+                              unsigned* status, hipStream_t st) {
   PROF_LAUNCH("gcn_partial_reduce_kernel", (double)nblk * PART, 4.0 * nblk * PART, st,
               hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(1024), 0, st, partial, nblk,
-                                 13, dW1, db1, dW2, db2));
+                                 13, dW1, db1, dW2, db2, status));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -403,7 +405,7 @@ int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const flo
                                  b1, W2, g, dg, (float*)nullptr, partial, ldg));
   WGNN_CHECK_LAUNCH();
   hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(1024), 0, st, partial, grid, 13, dW1,
-                     db1, dW2, db2);
+                     db1, dW2, db2, (unsigned*)nullptr);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -415,7 +417,7 @@ int launch_gcn1_bwd(int ntiles, int S, const float* A, const float* X, const flo
                      (const float*)nullptr, (const float*)nullptr, out, dout, dX, partial, S * 13);
   WGNN_CHECK_LAUNCH();
   hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(1024), 0, st, partial, grid, 13, dW,
-                     db, (float*)nullptr, (float*)nullptr);
+                     db, (float*)nullptr, (float*)nullptr, (unsigned*)nullptr);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

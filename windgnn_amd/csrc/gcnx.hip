@@ -182,10 +182,11 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const float* __restrict__ b2, _Float16* __restrict__ ghi,
-                                                       _Float16* __restrict__ glo, int ldp) {
+                                                       _Float16* __restrict__ glo, int ldp, unsigned* status) {
   constexpr int KS = (NT + 1) / 2;
   constexpr int SP = 16 * NT;
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
+  bool bad = false;            // a pre-activation outside fp16's range (or NaN: an operand already overflowed)
   static_assert(128 * NP >= (SP * F13 + 1 + 31) / 32 * 32, "pair map must cover the padded row");
   constexpr int NF = NT * KS;
   __shared__ __attribute__((aligned(16))) h8 sCA[2 * NF * 64];   // A fragments [frag][hi|lo][lane]
@@ -273,7 +274,11 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ht[n][r] = fmaxf(acc[r] + bb1[r], 0.f);
+      for (int r = 0; r < 4; ++r) {
+        const float z = acc[r] + bb1[r];
+        bad |= out_of_fp16_range(z);
+        Ht[n][r] = fmaxf(z, 0.f);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) U[i] = mfma3<X3>(frag_of<X3>(Ht[i], zero4), FW2, zero4);   // U2 row-tile i [s][f']
@@ -286,7 +291,11 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
       f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bb2[r], 0.f);
+      for (int r = 0; r < 4; ++r) {
+        const float z = acc[r] + bb2[r];
+        bad |= out_of_fp16_range(z);
+        v[r] = fmaxf(z, 0.f);
+      }
       *(f32x4*)(ob + (16 * n + c) * XS + 4 * g) = v;           // g^T[f' = 4g..4g+3][s] -> staged [s][f']
     }
     wave_lds_fence();
@@ -315,6 +324,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       }
     }
   }
+  report_status(status, bad, WGNN_STATUS_ACT_RANGE);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,7 +578,8 @@ size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)256 * PART; }
 int gcnx_bwd_grid(int ntiles, int S) { return grid_x(ntiles, S); }
 
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, hipStream_t st) {
+                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status,
+                     hipStream_t st) {
   _Float16* ghi = (_Float16*)g_planes;
   _Float16* glo = ghi + (size_t)ntiles * ldg;
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
@@ -580,11 +591,11 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const fl
   if (x3)                                                                                                         \
     PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                           \
                 hipLaunchKernelGGL((gcnx_fwd_kernel<NT, true>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, b2, \
-                                   ghi, glo, ldg));                                                               \
+                                   ghi, glo, ldg, status));                                                       \
   else                                                                                                            \
     PROF_LAUNCH("gcnx_fwd_kernel<" #NT ",f16>", fl, by * 0.75, st,                                                \
                 hipLaunchKernelGGL((gcnx_fwd_kernel<NT, false>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, \
-                                   b2, ghi, glo, ldg))
+                                   b2, ghi, glo, ldg, status))
   switch ((S + 15) / 16) {
     case 1: FWD_CASE(1); break;
     case 2: FWD_CASE(2); break;
@@ -602,7 +613,8 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const fl
                      int scale_in, float* partial, bool x3, hipStream_t st) {
   const _Float16* g = (const _Float16*)g_planes;   // hi plane carries the sign: g > 0 <=> hi > 0
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
-  const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
+  // what the launch reads: X and dg as fp32, and the fp16 hi plane of g (2 bytes x ldg per tile) as the ReLU mask
+  const double by = (double)ntiles * (S * 13 * 4.0 * 2.0 + ldg * 2.0);
   const dim3 grid(grid_x(ntiles, S));
 #define BWD_CASE(NT)                                                                                               \
   if (x3)                                                                                                          \

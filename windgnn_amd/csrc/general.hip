@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(ROWS) csr_layer_fwd_kernel(int ntiles, int S, 
                                                              size_t ld_in, const float* __restrict__ W,
                                                              const float* __restrict__ b, float* __restrict__ Out,
                                                              size_t ld_out, _Float16* __restrict__ Ohi,
-                                                             _Float16* __restrict__ Olo) {
+                                                             _Float16* __restrict__ Olo, unsigned* status) {
+  bool bad = false;
   __shared__ float Ws[F13 * F13], bs[F13];
   for (int i = threadIdx.x; i < F13 * F13; i += ROWS) Ws[i] = W[i];
   if (threadIdx.x < F13) bs[threadIdx.x] = b[threadIdx.x];
@@ -70,6 +71,7 @@ __global__ void __launch_bounds__(ROWS) csr_layer_fwd_kernel(int ntiles, int S, 
       a = fmaxf(a, 0.f);
       const size_t o = (size_t)tile * ld_out + (size_t)s * F13 + c;
       if (PLANES) {
+        bad |= out_of_fp16_range(a);
         const _Float16 h = (_Float16)a;
         Ohi[o] = h;
         if (Olo) Olo[o] = (_Float16)(a - (float)h);
@@ -78,6 +80,7 @@ __global__ void __launch_bounds__(ROWS) csr_layer_fwd_kernel(int ntiles, int S, 
       }
     }
   }
+  if (PLANES) report_status(status, bad, WGNN_STATUS_ACT_RANGE);
 }
 
 // One backward layer for a block's share of (tile, row-block) items:
@@ -333,24 +336,24 @@ size_t gcn_csr_bwd_partial_floats() { return (size_t)GEN_BLOCKS * PART; }
 // g: fp32 [ntiles][ldg], or (g_planes != nullptr) fp16 hi/lo planes [ntiles][ldg] each (lo skipped if !x3)
 int launch_gcn2_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W1, const float* b1,
                         const float* W2, const float* b2, float* h1, float* g, void* g_planes, size_t ldg, bool x3,
-                        hipStream_t st) {
+                        unsigned* status, hipStream_t st) {
   const Csr A = csr_of(csr, S, nnz, false);
   const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
   const double fl = (double)ntiles * (2.0 * nnz * F13 + 2.0 * S * F13 * F13), by = (double)ntiles * S * F13 * 8.0;
   const size_t I = (size_t)S * F13;
   PROF_LAUNCH("csr_layer_fwd_kernel", fl, by, st,
               hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(ROWS), 0, st, ntiles, S, A, X, I, W1, b1, h1, I,
-                                 (_Float16*)nullptr, (_Float16*)nullptr));
+                                 (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr));
   WGNN_CHECK_LAUNCH();
   if (g_planes) {
     _Float16* hi = (_Float16*)g_planes;
     PROF_LAUNCH("csr_layer_fwd_kernel", fl, by, st,
                 hipLaunchKernelGGL(csr_layer_fwd_kernel<true>, grid, dim3(ROWS), 0, st, ntiles, S, A, h1, I, W2, b2,
-                                   (float*)nullptr, ldg, hi, x3 ? hi + (size_t)ntiles * ldg : (_Float16*)nullptr));
+                                   (float*)nullptr, ldg, hi, x3 ? hi + (size_t)ntiles * ldg : (_Float16*)nullptr, status));
   } else {
     PROF_LAUNCH("csr_layer_fwd_kernel", fl, by, st,
                 hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(ROWS), 0, st, ntiles, S, A, h1, I, W2, b2, g,
-                                   ldg, (_Float16*)nullptr, (_Float16*)nullptr));
+                                   ldg, (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr));
   }
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
@@ -374,7 +377,7 @@ int launch_gcn2_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float
                                  I, h1, (const _Float16*)nullptr, I, du, I, (const float*)nullptr, (float*)nullptr,
                                  scales, partial));
   WGNN_CHECK_LAUNCH();
-  return launch_gcn_partial_reduce(partial, GEN_BLOCKS, dW1, db1, dW2, db2, st);
+  return launch_gcn_partial_reduce(partial, GEN_BLOCKS, dW1, db1, dW2, db2, nullptr, st);
 }
 
 // Y, gates from GI: per step gh = Hprev W_hh^T + b_hh (GEMM, skipped at t = 0 where h = 0) and the cell.
@@ -482,7 +485,7 @@ int launch_gcn1_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float
   const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
   const size_t I = (size_t)S * F13;
   hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(ROWS), 0, st, ntiles, S, A, X, I, W, b, out, I,
-                     (_Float16*)nullptr, (_Float16*)nullptr);
+                     (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -497,7 +500,7 @@ int launch_gcn1_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float
   hipLaunchKernelGGL((csr_layer_bwd_kernel<true>), dim3(GEN_BLOCKS), dim3(ROWS), 0, st, ntiles, S, A, AT, X, I, out,
                      (const _Float16*)nullptr, I, dout, I, W, du, (const float*)nullptr, partial);
   WGNN_CHECK_LAUNCH();
-  int rc = launch_gcn_partial_reduce(partial, GEN_BLOCKS, nullptr, nullptr, dW, db, st);   // the "layer 2" slots
+  int rc = launch_gcn_partial_reduce(partial, GEN_BLOCKS, nullptr, nullptr, dW, db, nullptr, st);   // the "layer 2" slots
   if (rc != WGNN_OK || !dX) return rc;
   const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
   hipLaunchKernelGGL(csr_spmm_kernel, grid, dim3(ROWS), 0, st, ntiles, S, AT, du, dX);

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
                                                             const float* __restrict__ Whh,
                                                             const float* __restrict__ bhh, float* __restrict__ Y,
                                                             float* __restrict__ gates, _Float16* __restrict__ yp_hi,
-                                                            _Float16* __restrict__ yp_lo) {
+                                                            _Float16* __restrict__ yp_lo, unsigned* status) {
   constexpr int HP = 32 * KS;                      // plane row width (halfs): h, then 1.0 at column H, then 0
   constexpr int HS = 32 * KS + 8;                  // row stride in halfs: 16-B aligned, conflict-free reads
   // h state is double-buffered: step t reads buffer t&1 and writes h_t into the other one, so a single
@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   const int jc = jv ? j : H - 1;
   const int b0 = blockIdx.x * MB;
 
+  bool wbad = false;
   Frag WB[3][KS];                                  // B operand: W_hh[(gate*H + j)][k], k = 32ks + 8g + jj
 #pragma unroll
   for (int gate = 0; gate < 3; ++gate)
@@ -108,9 +109,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       for (int jj = 0; jj < 8; ++jj) {
         const int k = 32 * ks + 8 * g + jj;
         x[jj] = (jv && k < H) ? Whh[(size_t)(gate * H + j) * H + k] : 0.f;
+        wbad |= out_of_fp16_range(x[jj]);
       }
       WB[gate][ks] = split_vals(x);
     }
+  if (blockIdx.x == 0) report_status(status, wbad, WGNN_STATUS_WEIGHT_RANGE);
   const float bh_r = bhh[jc], bh_z = bhh[H + jc], bh_n = bhh[2 * H + jc];
 
   // Addressing: one workgroup-uniform 64-bit base per array (the workgroup's first window) plus 32-bit lane
@@ -366,7 +369,8 @@ bool grux_shape_supported(int H) { return H >= 1 && H <= 127; }
 int grux_hp(int H) { return 32 * cdiv_i(H + 1, 32); }
 
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                    float* gates, void* y_planes /*nullable: 2 x [B*T+1][grux_hp(H)] halfs*/, bool x3, hipStream_t st) {
+                    float* gates, void* y_planes /*nullable: 2 x [B*T+1][grux_hp(H)] halfs*/, bool x3, unsigned* status,
+                    hipStream_t st) {
   _Float16* yh = (_Float16*)y_planes;
   _Float16* yl = yh ? yh + ((size_t)B * T + 1) * grux_hp(H) : nullptr;   // each plane has B*T + 1 rows
   const double bt = (double)B * T;
@@ -376,11 +380,11 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
   if (x3)                                                                                                          \
     PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                             \
                 hipLaunchKernelGGL((grux_fwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, \
-                                   Y, gates, yh, yl));                                                             \
+                                   Y, gates, yh, yl, status));                                                     \
   else                                                                                                             \
     PROF_LAUNCH("grux_fwd_kernel<" #K ",f16>", fl, by, st,                                                         \
                 hipLaunchKernelGGL((grux_fwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh,    \
-                                   bhh, Y, gates, yh, yl))
+                                   bhh, Y, gates, yh, yl, status))
   switch (cdiv_i(H + 1, 32)) {
     case 1: FCASE(1); break;
     case 2: FCASE(2); break;

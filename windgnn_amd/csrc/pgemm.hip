@@ -357,7 +357,8 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
 // summation tree over z is fixed, so the result is deterministic.  Four threads (z phases) per accumulator quad.
 __global__ void tn_reduce_kernel(const float* __restrict__ partial, int splitk, int T, int nNb, int ntiles, int Mout,
                                  int Nout, float* __restrict__ C, int ldc, int ncols_main,
-                                 float* __restrict__ bias_out, const float* __restrict__ scales) {
+                                 float* __restrict__ bias_out, const float* __restrict__ scales,
+                                 unsigned* status) {
   const size_t slab4 = (size_t)ntiles * TN_WAVES * 5 * T * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 quads x 4 z phases per block
   const size_t q = (size_t)blockIdx.x * 64 + tx;                     // slab4 is a multiple of 64
@@ -387,20 +388,23 @@ __global__ void tn_reduce_kernel(const float* __restrict__ partial, int splitk, 
   const int n = nb * 32 * T + 16 * (T * wn + j) + (lane & 15);
   const int m0 = mb * TN_BM + 80 * wm + 16 * i + 4 * (lane >> 4);
   if (n >= Nout) return;
+  bool bad = false;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = m0 + r;
     if (m >= Mout) continue;
+    bad |= !(__builtin_fabsf(s[r]) <= 3.0e38f);                      // inf / NaN in a final gradient
     if (n < ncols_main) C[(size_t)m * ldc + n] = s[r];
     else if (bias_out && n == Nout - 1) bias_out[m] = s[r];
   }
+  report_status(status, bad, WGNN_STATUS_GRAD_NONFINITE);
 }
 
 // Planes of O[Rp][Cp] (O[r][c] = transpose ? W[c][r] : W[r][c]; optional extra column `bias_col`
 // holding bias[r]; zero elsewhere) from fp32 W[R][C], STAGE-MAJOR: (r,c) at [(c/32)][r][c%32].
 __global__ void split_weight2_kernel(const float* __restrict__ W, int R, int C, int transpose,
                                      const float* __restrict__ bias, int bias_col, _Float16* hi, _Float16* lo,
-                                     int Rp, int Cp) {
+                                     int Rp, int Cp, unsigned* status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Rp * Cp) return;
   const int kt = i / (Rp * 32), rem = i % (Rp * 32);
@@ -414,18 +418,19 @@ __global__ void split_weight2_kernel(const float* __restrict__ W, int R, int C, 
   const _Float16 h = (_Float16)v;
   hi[i] = h;
   lo[i] = (_Float16)(v - (float)h);
+  report_status(status, out_of_fp16_range(v), WGNN_STATUS_WEIGHT_RANGE);
 }
 
 }  // namespace
 
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
-                         int Rp, int Cp, hipStream_t st) {
+                         int Rp, int Cp, unsigned* status, hipStream_t st) {
   _Float16* hi = (_Float16*)planes;
   _Float16* lo = hi + (size_t)Rp * Cp;
   const int n = Rp * Cp;
   PROF_LAUNCH("split_weight2_kernel", 0.0, 4.0 * R * C + 4.0 * n, st,
               hipLaunchKernelGGL(split_weight2_kernel, dim3(cdiv_i(n, 256)), dim3(256), 0, st, W, R, C, transpose,
-                                 bias, bias_col, hi, lo, Rp, Cp));
+                                 bias, bias_col, hi, lo, Rp, Cp, status));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -569,14 +574,14 @@ size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk) {
 
 // C[Mout][ldc] columns [0, ncols_main) and bias_out (column Nout-1) = scales[1] * sum over z of launch_pgemm_tn's partials.
 int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
-                           float* bias_out, const float* scales, hipStream_t st) {
+                           float* bias_out, const float* scales, unsigned* status, hipStream_t st) {
   int nNb, T;
   tn_shape(Nout, nNb, T);
   const int ntiles = cdiv_i(Mout, TN_BM) * nNb;
   const size_t slab4 = (size_t)ntiles * TN_WAVES * 5 * T * 64;
   PROF_LAUNCH("tn_reduce_kernel", (double)slab4 * 4 * splitk, 16.0 * slab4 * splitk + 4.0 * Mout * Nout, st,
               hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(slab4 / 64)), dim3(256), 0, st, partial,
-                                 splitk, T, nNb, ntiles, Mout, Nout, C, ldc, ncols_main, bias_out, scales));
+                                 splitk, T, nNb, ntiles, Mout, Nout, C, ldc, ncols_main, bias_out, scales, status));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

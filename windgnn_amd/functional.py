@@ -31,14 +31,26 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _adj(A):
-    """(device tensor to pass, adj_format, nnz) for a dense [S,S] tensor or a graph.CsrAdjacency."""
+def _adj(A, S=None):
+    """(device tensor to pass, adj_format, nnz) for a dense [S,S] tensor or a graph.CsrAdjacency.  `S` = the station
+    count of the features it will multiply: the kernels locate rowptr / col / val inside the CSR buffer from S and
+    nnz alone and the C ABI cannot look into device memory, so a buffer built for another graph is refused HERE."""
     if hasattr(A, "blob"):                                    # CsrAdjacency
+        if A.blob.dtype != torch.int32 or A.blob.dim() != 1 or not A.blob.is_contiguous():
+            raise RuntimeError("windgnn_amd: the CSR adjacency buffer must be a contiguous 1-D int32 tensor, got %s %s"
+                               % (A.blob.dtype, tuple(A.blob.shape)))
+        if A.blob.numel() != 2 * (A.S + 1) + 4 * A.nnz:
+            raise RuntimeError("windgnn_amd: CSR adjacency buffer has %d words, expected 2*(S+1) + 4*nnz = %d "
+                               "(S=%d, nnz=%d)" % (A.blob.numel(), 2 * (A.S + 1) + 4 * A.nnz, A.S, A.nnz))
+        if S is not None and A.S != S:
+            raise RuntimeError("windgnn_amd: CSR adjacency of %d stations does not match %d stations" % (A.S, S))
         if not A.blob.is_cuda:
             raise RuntimeError("windgnn_amd: the CSR adjacency is on %s; call .to(device) first (no CPU fallback)"
                                % A.blob.device)
         return A.blob, _lib.ADJ_CSR, A.nnz
     _require_gpu(A)
+    if S is not None and tuple(A.shape) != (S, S):
+        raise RuntimeError("windgnn_amd: adjacency %s does not match %d stations" % (tuple(A.shape), S))
     return A.contiguous(), _lib.ADJ_DENSE, 0
 
 
@@ -50,28 +62,53 @@ def _params_struct(cls, tensors: Sequence[torch.Tensor]):
 
 
 class _Workspace:
-    """Per-device grow-only scratch, so the steady state does no allocation."""
+    """Per-device grow-only scratch, so the steady state does no allocation.  Allocated zeroed: its first 256 bytes
+    are the library's sticky status block (include/windgnn.h), which kernels only OR into."""
     _bufs = {}
 
     @classmethod
     def get(cls, device, nbytes: int) -> torch.Tensor:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
         buf = cls._bufs.get(key)
+        nbytes = max(nbytes, _lib.STATUS_BYTES)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+            status = buf[:_lib.STATUS_BYTES].clone() if buf is not None else None
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            if status is not None:
+                buf[:_lib.STATUS_BYTES] = status            # a pending report survives the re-allocation
             cls._bufs[key] = buf
         return buf
+
+
+_STATUS_TEXT = {1: "a graph-convolution pre-activation left fp16's range (|x| >= 65520) or was NaN",
+                2: "a GRU weight or bias lies outside fp16's range",
+                4: "a gradient came out inf / NaN"}
+
+
+def check_range_status(device=None) -> None:
+    """Read the status word of this process's workspaces on `device` (one 4-byte device-to-host copy each, so a
+    synchronisation) and raise if a kernel of the fp16-plane math modes (f16x3 / f16) reported a value it cannot
+    represent.  The reference's fp32 path has no such limit; the answer is never silently inf/NaN/0."""
+    for (index, _), buf in list(_Workspace._bufs.items()):
+        if device is not None and torch.device(device).index not in (None, index):
+            continue
+        word = int(buf[:4].view(torch.int32).item())
+        if word:
+            buf[:4].zero_()
+            what = "; ".join(t for b, t in _STATUS_TEXT.items() if word & b)
+            raise RuntimeError("windgnn_amd: %s (status %d: %s). The f16x3 / f16 math modes hold activations and "
+                               "weights as fp16 planes: normalise the inputs (the reference min-max-normalises "
+                               "every feature to [0, 1]) or use math='f32'."
+                               % (_lib.load().wgnn_strerror(-7).decode(), word, what))
 
 
 def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32, want_stash=True):
     """Y[B,T,H], stash = wgnn_fwd(...).  X is [B,T,S,F]."""
     lib = _lib.load()
     _require_gpu(X, *params)
-    A, fmt, nnz = _adj(A)
     B, T, S, F = X.shape
+    A, fmt, nnz = _adj(A, S)
     H = params[5].shape[1]
-    if fmt == _lib.ADJ_DENSE and tuple(A.shape) != (S, S):
-        raise RuntimeError("windgnn_amd: adjacency %s does not match %d stations" % (tuple(A.shape), S))
     d = _lib.Dims(B, T, S, F, H, math, fmt, nnz)
     ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
     if ws_bytes == 0:
@@ -122,6 +159,12 @@ class GCNGRUFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, X, math, *params):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[0]:
+            # the reference's autograd would propagate into attr_matrix / adj_matrix; this path has no dX / dA
+            # (neither requires grad in the reference loop) and must not drop a requested gradient silently
+            raise RuntimeError("windgnn_amd: GCN_GRU gives gradients for its 8 parameters only; attr_matrix / "
+                               "adj_matrix with requires_grad=True are not supported (detach them, or stack "
+                               "GraphConvLayer modules, which do return dX)")
         X = X.contiguous()
         params = tuple(p.contiguous() for p in params)
         need = any(ctx.needs_input_grad[3:])
@@ -154,11 +197,9 @@ class GraphConvFunction(torch.autograd.Function):
     def forward(ctx, A, X, W, b):
         lib = _lib.load()
         _require_gpu(X, W, b)
-        A, fmt, nnz = _adj(A)
         X, W, b = X.contiguous(), W.contiguous(), b.contiguous()
         S, F = X.shape[-2], X.shape[-1]
-        if fmt == _lib.ADJ_DENSE and A.shape != (S, S):
-            raise RuntimeError("windgnn_amd: adjacency %s does not match %d stations" % (tuple(A.shape), S))
+        A, fmt, nnz = _adj(A, S)
         nt = X.numel() // (S * F)
         out = torch.empty_like(X)
         if fmt == _lib.ADJ_CSR:

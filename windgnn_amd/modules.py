@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .functional import GraphConvFunction, gcn_gru
+from .functional import GraphConvFunction, check_range_status, gcn_gru
 
 NUM_FEATURES = 13   # hard-coded in the reference: src/step6_gcn_gru_combined_model.py:16
 
@@ -50,8 +50,11 @@ class GCN_GRU(nn.Module):
     reference's contract.  Extension: attr_matrix [B,T,S,13] with B > 1 returns [B,T,H] (B
     independent windows, h0 = 0 each)."""
 
-    def __init__(self, input_dim, hidden_dim, output_dim, gru_input, gru_hidden_dim, math="f32"):
+    def __init__(self, input_dim, hidden_dim, output_dim, gru_input, gru_hidden_dim, math="f32", validate=True):
         super().__init__()
+        # validate: in the fp16-plane modes read the library's range-status word after every forward (one 4-byte
+        # device-to-host copy) and raise instead of returning inf/NaN-derived values; TrainStep checks every N steps
+        self.validate = validate
         if not (input_dim == hidden_dim == output_dim == NUM_FEATURES):
             raise RuntimeError("GCN_GRU: the reference hard-codes 13 features per station "
                                "(src/step6_gcn_gru_combined_model.py:16); got %s"
@@ -75,4 +78,6 @@ class GCN_GRU(nn.Module):
             raise RuntimeError("shape '[%d, %d, %d]' is invalid for input of size %d"
                                % (B, T, self.gru.input_size, attr_matrix.numel()))
         out = gcn_gru(adj_matrix, attr_matrix, self.hot_path_parameters(), self.math)
+        if self.validate and self.math != _lib.MATH_F32:
+            check_range_status(out.device)
         return out.squeeze(0)            # step6:26
