@@ -127,6 +127,14 @@ size_t wgnn_stash_bytes(const wgnn_dims* d);
 int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, float* Y,
              void* stash, void* workspace, size_t workspace_bytes, void* stream);
 
+/* wgnn_fwd for a training step whose loss is nn.MSELoss()(Y, labels) (src/main.py:66 + :72): the same Y and stash,
+ * and where the forward recurrence holds every h_t in registers anyway (f16x3 / f16, H <= 127) it also reduces
+ * (Y - labels) to per-workgroup partial sums of squares and maxima inside the stash, so that
+ * wgnn_bwd_mse_part(..., part | 8) needs no pass over Y and the labels for the loss and the range scale.  On every
+ * other shape it is exactly wgnn_fwd (and the backward ignores bit 8).  stash must not be NULL. */
+int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* labels,
+                  float* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Gradients of sum(Y * dY) w.r.t. the 8 parameters (overwritten, not accumulated).
  * No dX and no dA: neither requires grad in the reference (src/main.py:26,
  * src/step4_sequence_preparer.py:58). */
@@ -154,7 +162,7 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
 int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p,
                       const float* Y, const float* labels /* [B,T,H] */, float grad_scale, float* loss,
                       const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
-                      void* stream, int part /* bit mask 1..7 */);
+                      void* stream, int part /* bit mask 1..7, + 8: the forward was wgnn_fwd_loss on these labels */);
 
 /* One GraphConvLayer: out[n,S,F] = relu(A X[n] W + b) for n = 0..ntiles-1 (ntiles = prod of the
  * leading dims of attr_matrix).  Backward: dW, db (overwritten) and, if dX != NULL, dX. */

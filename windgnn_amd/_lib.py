@@ -39,6 +39,8 @@ EXPORTS = {
     "wgnn_stash_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "wgnn_fwd": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wgnn_fwd_loss": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "wgnn_bwd": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                            C.c_void_p, C.POINTER(Grads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "wgnn_bwd_part": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,

@@ -22,6 +22,7 @@ struct Layout {
   bool x3, gen_gcn, gen_gru;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
   size_t st_h1;                                  // general GCN: layer-1 activations
+  size_t st_stats;                               // wgnn_fwd_loss: MSE partial pairs (sum | max) of the forward recurrence
   size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_kp_f, ws_hc, ws_du, ws_dhz, ws_dhw, ws_hhp_b, ws_kp_b, ws_dc;   // general GRU / GCN scratch
 };
 
@@ -69,6 +70,7 @@ Layout make_layout(const wgnn_dims* d) {
   L.st_gates = o; o += al(L.BT * 4 * L.H);
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
   L.st_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
+  L.st_stats = o; o += al(2 * (size_t)grux_blocks(d->B));
   L.stash_floats = o;
   if (x3) {
     L.sk_ih = pick_splitk(L.BT, pgemm_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64);   // one workgroup per CU
@@ -160,8 +162,8 @@ size_t wgnn_stash_bytes(const wgnn_dims* d) {
   return sizeof(float) * make_layout(d).stash_floats;
 }
 
-int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, float* Y, void* stash,
-             void* workspace, size_t workspace_bytes, void* stream) {
+static int fwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* labels,
+                    float* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
   if (!A || !X || !p || !Y || !workspace) return WGNN_ERR_NULL;
@@ -204,8 +206,9 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
                                    sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, ws + L.ws_kp_f, ws + L.ws_hc, full,
                                    st);
     }
+    // labels (wgnn_fwd_loss): the recurrence also leaves the MSE partial sums / maxima of (Y - labels) in the stash
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
-                           full, status, st);
+                           full, status, sf ? labels : nullptr, sf ? sf + L.st_stats : nullptr, st);
   }
   if (L.gen_gcn) {
     float* h1 = sf ? sf + L.st_h1 : ws + L.ws_h1;    // layer-1 activations: kept for the backward if there is a stash
@@ -228,6 +231,17 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, st);
 }
 
+int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, float* Y, void* stash,
+             void* workspace, size_t workspace_bytes, void* stream) {
+  return fwd_impl(d, A, X, p, nullptr, Y, stash, workspace, workspace_bytes, stream);
+}
+
+int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* labels,
+                  float* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!labels || !stash) return WGNN_ERR_NULL;
+  return fwd_impl(d, A, X, p, labels, Y, stash, workspace, workspace_bytes, stream);
+}
+
 int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
              const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
              void* stream) {
@@ -242,8 +256,9 @@ namespace {
 int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
              const float* dY, const float* labels, float grad_scale, float* loss, const void* stash,
              const wgnn_grads* g, void* workspace, size_t workspace_bytes, void* stream, int which) {
-  if (which < 1 || which > 7) return WGNN_ERR_SHAPE;
+  if (which < 1 || which > 15 || (which & 7) == 0) return WGNN_ERR_SHAPE;
   const bool do_rec = which & 1, do_gcn = which & 2, do_wg = which & 4;
+  const bool stats_ready = (which & 8) && labels;   // wgnn_fwd_loss left the MSE partials in the stash
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
   if (!A || !X || !p || !Y || (!dY && !labels) || !stash || !g || !workspace) return WGNN_ERR_NULL;
@@ -282,7 +297,10 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
     const _Float16* yph = (const _Float16*)(sf + L.st_yp);
     const size_t PG = L.BT * L.Gp;
     if (do_rec) {
-      if (fused_loss)   // loss, the range scale and the dY coefficient in one pass over Y and the labels
+      if (fused_loss && stats_ready)   // the forward recurrence already reduced (Y - labels): only the 1-block finalize
+        rc = launch_mse_stats_finalize(sf + L.st_stats, grux_blocks(d->B), (int64_t)L.BT * L.H, grad_scale, loss, scales,
+                                       st);
+      else if (fused_loss)   // loss, the range scale and the dY coefficient in one pass over Y and the labels
         rc = launch_mse_stats(Y, labels, (int64_t)L.BT * L.H, grad_scale, loss, scales, scales + 64, st);
       else
         rc = launch_amax_scale(dY, (int64_t)L.BT * L.H, scales, scales + 64, st);   // 448 partials after the scales

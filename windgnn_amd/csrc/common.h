@@ -106,7 +106,13 @@ int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                    float* gates, void* y_planes, bool x3, unsigned* status, hipStream_t st);
+                    float* gates, void* y_planes, bool x3, unsigned* status, const float* labels, float* stat_part,
+                    hipStream_t st);
+int grux_blocks(int B);   // workgroups of launch_grux_fwd = MSE partial pairs it writes when given labels
+// loss and scales {2^k, 2^-k, 2 grad_scale / n} from nblk partial pairs (sum | max) already computed
+int launch_mse_stats_finalize(const float* part, int nblk, int64_t n, float grad_scale, float* loss, float* scales,
+                              hipStream_t st);
+int mse_stats_blocks();
 // exactly one of dY / labels is non-null (labels: dY = (Y - labels) * scales[2], see launch_mse_stats)
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
                     const float* gates,

@@ -59,12 +59,15 @@ __device__ __forceinline__ unsigned cvt2(float x0, float x1) {
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
   float t0, t1;
   hi = cvt2(x0, x1);
-  asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_cvt_pk_f16_f32 %0, %1, %2\n\t"
-      "s_nop 1"   // VALU write -> MFMA operand read needs 2 wait states; hipcc pads nothing inside/after asm
-      : "=&v"(lo), "=&v"(t0), "=&v"(t1)
+  // only the two v_fma_mix_f32 (no C expression selects them) are asm; the conversion of their results is a
+  // compiler-visible v_cvt_pk_f16_f32 again, so the VALU-write -> MFMA-operand wait states are the hazard
+  // recognizer's business (it fills them with independent instructions; an `s_nop 1` inside the asm could not be
+  // scheduled around: 82 of the 713 instructions of a backward tile were such nops)
+  asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(t0), "=&v"(t1)
       : "v"(hi), "v"(x0), "v"(x1));
+  lo = cvt2(t0, t1);
 }
 template <bool X3>
 __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
@@ -89,6 +92,8 @@ __device__ __forceinline__ Frag frag_of(f32x4 t0, f32x4 t1) {
   const float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
   return split_vals<X3>(x);
 }
+// max(z, 0) for finite z; NaN for z = NaN or +-inf (0 * z is +-0 or NaN): one v_fma more than the plain ReLU
+__device__ __forceinline__ float relu_nan(float z) { return __builtin_fmaf(z, 0.f, fmaxf(z, 0.f)); }
 __device__ __forceinline__ int rho(int ks, int g, int j) { return 16 * (2 * ks + (j >> 2)) + 4 * g + (j & 3); }
 
 // "A [m = s][k = s']" fragments in rho order (also the B operand of any product with A^T)
@@ -169,9 +174,9 @@ template <bool X3>
 __device__ __forceinline__ Frag xfrag_nat(const float* xb, int i, int c, int g) {
   const f32x4 v0 = *(const f32x4*)(xb + (16 * i + c) * XS + 8 * (g & 1));
   const f32x4 v1 = *(const f32x4*)(xb + (16 * i + c) * XS + 8 * (g & 1) + 4);
-  const bool on = g < 2;                       // k = 8g + j >= 16 for g >= 2: zero
-  const float x[8] = {on ? v0[0] : 0.f, on ? v0[1] : 0.f, on ? v0[2] : 0.f, on ? v0[3] : 0.f,
-                      on ? v1[0] : 0.f, on ? v1[1] : 0.f, on ? v1[2] : 0.f, on ? v1[3] : 0.f};
+  // lane groups g >= 2 (k = 8g + j >= 16) hold a second copy of the same finite data: every B operand this fragment
+  // meets (W1, W2^T) is zero for k >= 13, so no select is needed to zero them
+  const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
   return split_vals<X3>(x);
 }
 
@@ -186,7 +191,12 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
   constexpr int KS = (NT + 1) / 2;
   constexpr int SP = 16 * NT;
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
-  bool bad = false;            // a pre-activation outside fp16's range (or NaN: an operand already overflowed)
+  // Range check (status block, include/windgnn.h).  A pre-activation z is inf / NaN exactly when an operand overflowed
+  // fp16 upstream, and the ReLU's fmaxf(NaN, 0) = 0 would hide that: relu_nan() adds 0 * z, which is +-0 for finite z
+  // and NaN otherwise, so the poison reaches the stored value; there chk collects 0 * (v - hi), NaN when v was NaN or
+  // rounded to the fp16 infinity.  (Compares or a checksum over the pre-activations themselves cost a wave of
+  // occupancy: the compiler sank them behind the tile's products and kept all 24 operands alive, 122 -> 160 VGPRs.)
+  float chk = 0.f;
   static_assert(128 * NP >= (SP * F13 + 1 + 31) / 32 * 32, "pair map must cover the padded row");
   constexpr int NF = NT * KS;
   __shared__ __attribute__((aligned(16))) h8 sCA[2 * NF * 64];   // A fragments [frag][hi|lo][lane]
@@ -275,9 +285,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float z = acc[r] + bb1[r];
-        bad |= out_of_fp16_range(z);
-        Ht[n][r] = fmaxf(z, 0.f);
+        Ht[n][r] = relu_nan(acc[r] + bb1[r]);
       }
     }
 #pragma unroll
@@ -292,9 +300,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float z = acc[r] + bb2[r];
-        bad |= out_of_fp16_range(z);
-        v[r] = fmaxf(z, 0.f);
+        v[r] = relu_nan(acc[r] + bb2[r]);
       }
       *(f32x4*)(ob + (16 * n + c) * XS + 4 * g) = v;           // g^T[f' = 4g..4g+3][s] -> staged [s][f']
     }
@@ -315,7 +321,9 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
           v1 = e + 1 < I ? v1 : (e + 1 == I ? 1.f : 0.f);
           h2 hi, lo;
           hi[0] = (_Float16)v0; hi[1] = (_Float16)v1;
-          lo[0] = (_Float16)(v0 - (float)hi[0]); lo[1] = (_Float16)(v1 - (float)hi[1]);
+          const float d0 = v0 - (float)hi[0], d1 = v1 - (float)hi[1];   // -inf where the value rounded to fp16's inf
+          chk = __builtin_fmaf(d0, 0.f, __builtin_fmaf(d1, 0.f, chk));
+          lo[0] = (_Float16)d0; lo[1] = (_Float16)d1;
           if (p < ldp / 2) {
             dh[p] = __builtin_bit_cast(unsigned, hi);
             if (X3) dl[p] = __builtin_bit_cast(unsigned, lo);
@@ -324,7 +332,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       }
     }
   }
-  report_status(status, bad, WGNN_STATUS_ACT_RANGE);
+  report_status(status, chk != chk, WGNN_STATUS_ACT_RANGE);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -76,7 +76,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
                                                             const float* __restrict__ Whh,
                                                             const float* __restrict__ bhh, float* __restrict__ Y,
                                                             float* __restrict__ gates, _Float16* __restrict__ yp_hi,
-                                                            _Float16* __restrict__ yp_lo, unsigned* status) {
+                                                            _Float16* __restrict__ yp_lo, unsigned* status,
+                                                            const float* __restrict__ Lab,
+                                                            float* __restrict__ stat_part) {
   constexpr int HP = 32 * KS;                      // plane row width (halfs): h, then 1.0 at column H, then 0
   constexpr int HS = 32 * KS + 8;                  // row stride in halfs: 16-B aligned, conflict-free reads
   // h state is double-buffered: step t reads buffer t&1 and writes h_t into the other one, so a single
@@ -129,8 +131,13 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     rowok[r] = jv && b0 + m < B;
     rowt[r] = (b0 + m < B ? m : B - 1 - b0) * T;
   }
+  // wgnn_fwd_loss: the MSE statistics (sum of squares, max |Y - L|) are taken here, from the h this kernel
+  // holds in registers, so no later pass re-reads Y and the labels for them
+  const float* Labw = Lab ? Lab + (size_t)b0 * T * H : nullptr;
+  float lab[4] = {0.f, 0.f, 0.f, 0.f}, labn[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssum = 0.f, smax = 0.f;
   float gi[3][4], gin[3][4];
-  auto load_gi = [&](int t, float (&dst)[3][4]) {
+  auto load_gi = [&](int t, float (&dst)[3][4], float (&ldst)[4]) {
     const int tc = t < T ? t : T - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -138,9 +145,10 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       dst[0][r] = GIw[o];
       dst[1][r] = GIw[o + H];
       dst[2][r] = GIw[o + 2 * H];
+      if (Lab) ldst[r] = Labw[(rowt[r] + tc) * H + jc];
     }
   };
-  load_gi(0, gi);
+  load_gi(0, gi, lab);
   float hold[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
@@ -149,7 +157,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     const _Float16* hlo = hhi + MB * HS;
     _Float16* nhi = hbuf + ((t + 1) & 1) * 2 * MB * HS;          // h_t goes here
     _Float16* nlo = nhi + MB * HS;
-    load_gi(t + 1, gin);                           // prefetch under this step's MFMAs
+    load_gi(t + 1, gin, labn);                     // prefetch under this step's MFMAs
     float hnew[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
       f32x4 ar, az, an;
@@ -178,6 +186,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         if (rowok[r]) {
           const int bt = rowt[r] + t;
           Yw[bt * H + j] = hnew[r];
+          if (Lab) {
+            const float dl = hnew[r] - lab[r];
+            ssum = fmaf(dl, dl, ssum);
+            smax = fmaxf(smax, fabsf(dl));
+          }
           if (gates) {
             const int o = bt * 4 * H + j;
             gatesw[o] = rg;
@@ -209,6 +222,31 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r) gi[q][r] = gin[q][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lab[r] = labn[r];
+  }
+  if (Lab) {   // block partials in a fixed order: lanes (xor tree), then the 8 waves
+    __shared__ float red[2][NTHREADS / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ssum += __shfl_xor(ssum, o, 64);
+      smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    }
+    if (lane == 0) {
+      red[0][wave] = ssum;
+      red[1][wave] = smax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = 0.f, m = 0.f;
+#pragma unroll
+      for (int w = 0; w < NTHREADS / 64; ++w) {
+        a += red[0][w];
+        m = fmaxf(m, red[1][w]);
+      }
+      stat_part[blockIdx.x] = a;
+      stat_part[gridDim.x + blockIdx.x] = m;
+    }
   }
 }
 
@@ -367,24 +405,26 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 bool grux_shape_supported(int H) { return H >= 1 && H <= 127; }
 
 int grux_hp(int H) { return 32 * cdiv_i(H + 1, 32); }
+int grux_blocks(int B) { return cdiv_i(B, MB); }
 
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
                     float* gates, void* y_planes /*nullable: 2 x [B*T+1][grux_hp(H)] halfs*/, bool x3, unsigned* status,
+                    const float* labels /*nullable*/, float* stat_part /*2 * grux_blocks(B) floats if labels*/,
                     hipStream_t st) {
   _Float16* yh = (_Float16*)y_planes;
   _Float16* yl = yh ? yh + ((size_t)B * T + 1) * grux_hp(H) : nullptr;   // each plane has B*T + 1 rows
   const double bt = (double)B * T;
-  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0));
+  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0) + (labels ? H : 0));
   const dim3 grid(cdiv_i(B, MB));
 #define FCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
     PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                             \
                 hipLaunchKernelGGL((grux_fwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, \
-                                   Y, gates, yh, yl, status));                                                     \
+                                   Y, gates, yh, yl, status, labels, stat_part));                                  \
   else                                                                                                             \
     PROF_LAUNCH("grux_fwd_kernel<" #K ",f16>", fl, by, st,                                                         \
                 hipLaunchKernelGGL((grux_fwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh,    \
-                                   bhh, Y, gates, yh, yl, status))
+                                   bhh, Y, gates, yh, yl, status, labels, stat_part))
   switch (cdiv_i(H + 1, 32)) {
     case 1: FCASE(1); break;
     case 2: FCASE(2); break;

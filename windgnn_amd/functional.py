@@ -27,6 +27,13 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _scratch(device, nbytes: int):
+    """(pointer, bytes) of plain scratch for the entry points that have no status block (wgnn_mse_loss_grad,
+    wgnn_gcn_layer_*_bwd): the shared workspace past its first 256 bytes."""
+    ws = _Workspace.get(device, nbytes + _lib.STATUS_BYTES)
+    return C.c_void_p(ws.data_ptr() + _lib.STATUS_BYTES), ws.numel() - _lib.STATUS_BYTES
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -102,8 +109,9 @@ def check_range_status(device=None) -> None:
                                % (_lib.load().wgnn_strerror(-7).decode(), word, what))
 
 
-def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32, want_stash=True):
-    """Y[B,T,H], stash = wgnn_fwd(...).  X is [B,T,S,F]."""
+def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32, want_stash=True, labels=None):
+    """Y[B,T,H], stash = wgnn_fwd(...).  X is [B,T,S,F].  labels [B,T,H]: wgnn_fwd_loss (the MSE statistics of
+    (Y - labels) are left in the stash for gcn_gru_backward_mse_raw(..., part | 8))."""
     lib = _lib.load()
     _require_gpu(X, *params)
     B, T, S, F = X.shape
@@ -117,6 +125,15 @@ def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32
     stash = torch.empty(lib.wgnn_stash_bytes(C.byref(d)), dtype=torch.uint8, device=X.device) if want_stash else None
     Y = torch.empty(B, T, H, dtype=torch.float32, device=X.device)
     ps = _params_struct(_lib.Params, params)
+    if labels is not None:
+        _require_gpu(labels)
+        if labels.numel() != Y.numel() or not want_stash:
+            raise RuntimeError("windgnn_amd: wgnn_fwd_loss needs a stash and labels of Y's size, got %s vs %s"
+                               % (tuple(labels.shape), tuple(Y.shape)))
+        rc = lib.wgnn_fwd_loss(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(labels.contiguous()), _ptr(Y),
+                               _ptr(stash), _ptr(ws), ws_bytes, _stream())
+        _lib.check(rc, "wgnn_fwd_loss")
+        return Y, stash, d
     rc = lib.wgnn_fwd(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(Y), _ptr(stash), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, "wgnn_fwd")
     return Y, stash, d
@@ -222,15 +239,15 @@ class GraphConvFunction(torch.autograd.Function):
         dX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
         if fmt == _lib.ADJ_CSR:
             nbytes = lib.wgnn_gcn_layer_csr_workspace_bytes(nt, S, F)
-            ws = _Workspace.get(X.device, nbytes)
+            wsp, _ = _scratch(X.device, nbytes)
             rc = lib.wgnn_gcn_layer_csr_bwd(nt, S, F, nnz, _ptr(A), _ptr(X), _ptr(W), _ptr(out), _ptr(dout), _ptr(dW),
-                                            _ptr(db), _ptr(dX), _ptr(ws), nbytes, _stream())
+                                            _ptr(db), _ptr(dX), wsp, nbytes, _stream())
             _lib.check(rc, "wgnn_gcn_layer_csr_bwd")
             return None, dX, dW, db
         nbytes = lib.wgnn_gcn_layer_workspace_bytes(nt, S, F)
-        ws = _Workspace.get(X.device, nbytes)
+        wsp, _ = _scratch(X.device, nbytes)
         rc = lib.wgnn_gcn_layer_bwd(nt, S, F, _ptr(A), _ptr(X), _ptr(W), _ptr(out), _ptr(dout), _ptr(dW), _ptr(db),
-                                    _ptr(dX), _ptr(ws), nbytes, _stream())
+                                    _ptr(dX), wsp, nbytes, _stream())
         _lib.check(rc, "wgnn_gcn_layer_bwd")
         return None, dX, dW, db
 
@@ -244,9 +261,8 @@ def mse_loss_grad(Y, L, grad_scale: float = 1.0, want_grad=True):
         raise RuntimeError("windgnn_amd: MSE operands differ in size: %s vs %s" % (tuple(Y.shape), tuple(L.shape)))
     dY = torch.empty_like(Y) if want_grad else None
     loss = torch.empty((), dtype=torch.float32, device=Y.device)
-    ws = _Workspace.get(Y.device, 4096)
-    rc = lib.wgnn_mse_loss_grad(_ptr(Y), _ptr(L), Y.numel(), grad_scale, _ptr(dY), _ptr(loss), _ptr(ws), ws.numel(),
-                                _stream())
+    wsp, wsn = _scratch(Y.device, 4096)
+    rc = lib.wgnn_mse_loss_grad(_ptr(Y), _ptr(L), Y.numel(), grad_scale, _ptr(dY), _ptr(loss), wsp, wsn, _stream())
     _lib.check(rc, "wgnn_mse_loss_grad")
     return loss, dY
 

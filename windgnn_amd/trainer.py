@@ -64,9 +64,9 @@ class TrainStep:
 
     def forward_backward(self, A, X, L):
         """src/main.py:66,72,79: returns (loss, Y); gradients land in the flat bucket."""
-        Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True)
+        Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True, labels=L)
         loss = self._loss
-        gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0)
+        gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0, part=7 | 8)
         return loss, Y
 
     def step(self, A, X, L):
@@ -75,9 +75,9 @@ class TrainStep:
             # their all-reduce runs on RCCL's stream while part 2 (dg GEMM + GCN backward, ~30 % of the
             # step) still computes; the 364 conv gradients and the loss follow in a second, tiny all-reduce.
             gs, equal = self._scales(X.shape[0])
-            Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True)
+            Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True, labels=L)
             loss = self._loss
-            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=1 | 4)
+            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=1 | 4 | 8)
             if not equal:
                 loss.mul_(gs * self.world)      # weight of this shard's mean in the global mean, times world
             work = torch.distributed.all_reduce(self.flat_g[self.n_conv:], group=self.group, async_op=True)
