@@ -21,7 +21,10 @@ struct Layout {
   // shapes beyond the fast kernels (CSR adjacency, wide hidden state) use general.hip in exact fp32
   bool x3, gen_gcn, gen_gru;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
+  bool dghn;                                     // fast f16x3 recurrence: only the n third of dGH is stored (dGHn planes)
+  int hn, msplit, m_hh;                          // its row width, its first GEMM row, GEMM rows of the dW_hh product
   size_t st_h1;                                  // general GCN: layer-1 activations
+  size_t st_mask;                                // dense f16x3 GCN: layer-2 ReLU mask bits for the backward
   size_t st_stats;                               // wgnn_fwd_loss: MSE partial pairs (sum | max) of the forward recurrence
   size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_kp_f, ws_hc, ws_du, ws_dhz, ws_dhw, ws_hhp_b, ws_kp_b, ws_dc;   // general GRU / GCN scratch
 };
@@ -71,10 +74,15 @@ Layout make_layout(const wgnn_dims* d) {
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
   L.st_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.st_stats = o; o += al(2 * (size_t)grux_blocks(d->B));
+  L.st_mask = o; o += al(x3 && !L.gen_gcn ? gcnx_mask_floats((int)L.BT) : 0);
   L.stash_floats = o;
+  L.dghn = x3 && !L.gen_gru;
+  L.hn = grux_hn(d->H);
+  L.msplit = grux_msplit(d->H);
+  L.m_hh = L.dghn ? L.msplit + L.hn : (int)L.G3;
   if (x3) {
     L.sk_ih = pick_splitk(L.BT, pgemm_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64);   // one workgroup per CU
-    L.sk_hh = pick_splitk(L.BT, pgemm_tn_tiles((int)L.G3, (int)L.H + 1), 256, 64);
+    L.sk_hh = pick_splitk(L.BT, pgemm_tn_tiles(L.m_hh, (int)L.H + 1), 256, 64);
   } else {
     L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128), 1024, 256);
     L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128), 1024, 256);
@@ -83,11 +91,11 @@ Layout make_layout(const wgnn_dims* d) {
   size_t part_hh = (size_t)L.sk_hh * L.G3 * (L.H + 1);
   if (x3) {
     part_ih = pgemm_tn_partial_floats((int)L.G3, (int)L.I + 1, L.sk_ih);
-    part_hh = pgemm_tn_partial_floats((int)L.G3, (int)L.H + 1, L.sk_hh);
+    part_hh = pgemm_tn_partial_floats(L.m_hh, (int)L.H + 1, L.sk_hh);
   }
   o = HDR;
   L.ws_dGI = o; o += al(L.BT * L.Gp);   // fp32, or hi+lo fp16 planes (same bytes)
-  L.ws_dGH = o; o += al(L.BT * L.Gp);
+  L.ws_dGH = o; o += al(L.dghn ? L.BT * (size_t)L.hn : L.BT * L.Gp);   // dGHn planes, or full dGH (general GRU / f32)
   L.ws_dg = o; o += al(L.BT * L.I);
   L.ws_part = o; o += al(part_ih > part_hh ? part_ih : part_hh);
   {
@@ -192,7 +200,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const float* X, const wg
                                p->conv2_bias, sf ? sf + L.st_h1 : ws + L.ws_h1, nullptr, g, L.Ip, full, status, st);
     else
       rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                            (int)L.Ip, full, status, st);
+                            (int)L.Ip, full, status, sf ? sf + L.st_mask : nullptr, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
@@ -318,19 +326,29 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
       if (rc != WGNN_OK) return rc;
     }
     if (do_wg) {
-      // dW_hh | db_hh = dGH^T [Hprev | 1]   (Hprev row (b,t) = Y-plane row (b,t-1); row B*T stands in at t = 0)
-      rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
-                           L.sk_hh, part, (int)L.G3, (int)L.H + 1, full, st);
-      if (rc != WGNN_OK) return rc;
-      rc = launch_pgemm_tn_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
-                                  status, st);
+      // dW_hh | db_hh = dGH^T [Hprev | 1]   (Hprev row (b,t) = Y-plane row (b,t-1); row B*T stands in at t = 0).
+      // Register-resident recurrence: dGH = [dGI_r | dGI_z | dGHn], the A operand takes GEMM rows < msplit from the dGI
+      // planes and rows >= msplit from the dGHn planes; the reduce kernel maps the GEMM rows back to W_hh's rows.
+      if (L.dghn) {
+        rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
+                             L.sk_hh, part, L.m_hh, (int)L.H + 1, full, dGHh, dGHh + L.BT * (size_t)L.hn, L.hn, L.msplit, st);
+        if (rc != WGNN_OK) return rc;
+        rc = launch_pgemm_tn_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
+                                    status, L.msplit, 2 * d->H, L.m_hh, st);
+      } else {
+        rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
+                             L.sk_hh, part, (int)L.G3, (int)L.H + 1, full, nullptr, nullptr, 0, 0, st);
+        if (rc != WGNN_OK) return rc;
+        rc = launch_pgemm_tn_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
+                                    status, 0, 0, (int)L.G3, st);
+      }
       if (rc != WGNN_OK) return rc;
       // dW_ih | db_ih = dGI^T [g | 1]
       rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part,
-                           (int)L.G3, (int)L.I + 1, full, st);
+                           (int)L.G3, (int)L.I + 1, full, nullptr, nullptr, 0, 0, st);
       if (rc != WGNN_OK) return rc;
       rc = launch_pgemm_tn_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales,
-                                  status, st);
+                                  status, 0, 0, (int)L.G3, st);
       if (rc != WGNN_OK) return rc;
     }   // the four GRU gradients are final here: a data-parallel caller can start reducing them now
     if (!do_gcn) return WGNN_OK;
@@ -345,7 +363,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
       return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
                                  L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
                                  g->conv2_weight, g->conv2_bias, st);
-    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
+    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, sf + L.st_mask, dg,
                           scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, st);
     if (rc != WGNN_OK) return rc;
     return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT, d->S), g->conv1_weight, g->conv1_bias,

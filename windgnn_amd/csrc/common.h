@@ -114,9 +114,12 @@ int launch_mse_stats_finalize(const float* part, int nblk, int64_t n, float grad
                               hipStream_t st);
 int mse_stats_blocks();
 // exactly one of dY / labels is non-null (labels: dY = (Y - labels) * scales[2], see launch_mse_stats)
+// dGI planes [B*T][ldd] (3H layout) and the n third of dGH alone, dGHn planes [B*T][grux_hn(H)] (dGH's r and z thirds equal dGI's)
+int grux_hn(int H);       // row width (halfs) of the dGHn planes: 8*ceil(H/8)
+int grux_msplit(int H);   // 8*ceil(2H/8): first GEMM row of the dGHn block in the dW_hh product
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
                     const float* gates,
-                    const float* scales, void* dGI_planes, void* dGH_planes, int ldd, bool x3, hipStream_t st);
+                    const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st);
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,
                     const float* b1, const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
@@ -132,9 +135,11 @@ size_t gcnx2_bwd_partial_floats(int ntiles);
 int gcnx_bwd_grid(int ntiles, int S);
 // g_planes: fp16 hi plane [ntiles][ldg] followed by the lo plane; column S*13 holds 1.0, later columns 0
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, hipStream_t st);
+                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status,
+                     void* gmask /*nullable: gcnx_mask_floats(ntiles) floats, the backward's ReLU mask bits*/, hipStream_t st);
+size_t gcnx_mask_floats(int ntiles);
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
+                     const float* W2, const void* gmask, const float* dg, const float* scales,
                      int scale_in, float* partial, bool x3, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
@@ -143,13 +148,16 @@ int pgemm_nt_np(int N);
 int pgemm_tn_tiles(int Mout, int Nout);   // output tiles per K chunk (sizes the split-K factor)
 size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk);
 int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
-                           float* bias_out, const float* scales, unsigned* status, hipStream_t st);
+                           float* bias_out, const float* scales, unsigned* status, int msplit, int rows1, int Mgemm,
+                           hipStream_t st);
 // kpart (nullable): pgemm_nt_kpart_floats(M, ldc, Kp) floats of split-K scratch for few-row, long-K products
 size_t pgemm_nt_kpart_floats(int M, int ldc, int Kp);
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
                     int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st);
+// A2hi != null: columns m >= msplit of the A operand are column m - msplit of the planes A2hi / A2lo (row stride lda2)
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
-                    int K, int splitk, float* partial, int Mout, int Nout, bool x3, hipStream_t st);
+                    int K, int splitk, float* partial, int Mout, int Nout, bool x3, const void* A2hi, const void* A2lo,
+                    int lda2, int msplit, hipStream_t st);
 // general shapes (general.hip): CSR adjacency (blob layout: see include/windgnn.h) and any hidden width
 size_t gcn_csr_bwd_partial_floats();
 int launch_gcn2_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W1, const float* b1,

@@ -255,19 +255,23 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
 //   dn = dh (1-z), dz = dh (hprev - n), dnt = dn (1-n^2), dr = dnt gh_n,
 //   dar = dr r (1-r), daz = dz z (1-z);  dgi = [dar, daz, dnt], dgh = [dar, daz, dnt r]
 //   dh_next = dh z + dgh W_hh
-template <int KS3, bool X3>   // K steps of 32 over the 3H gate rows
+// Outputs for the weight-gradient GEMMs: dGI planes [B*T][ldd] in the 3H layout, and of dGH ONLY its n third,
+// dGHn = dnt*r, planes [B*T][HN] (dGH's r and z thirds equal dGI's: the dW_hh GEMM takes them from the dGI planes).
+// In LDS the dgh row is laid out [dar | daz | pad to MS = 8*ceil(2H/8) | dnr] so that the dnr block is 16-byte aligned
+// for the copy-out; the W_hh^T fragments' k index follows the same layout.
+template <int KSB, bool X3>   // K steps of 32 over the padded dgh row: KSB = ceil((MS + H) / 32)
 __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
                                                             const float* __restrict__ Y, const float* __restrict__ dY,
                                                             const float* __restrict__ Lab,
                                                             const float* __restrict__ gates,
                                                             const float* __restrict__ scales,
                                                             _Float16* __restrict__ dGI_hi, _Float16* __restrict__ dGI_lo,
-                                                            _Float16* __restrict__ dGH_hi, _Float16* __restrict__ dGH_lo,
-                                                            int ldd) {
-  constexpr int DS = 32 * KS3 + 8;
-  // two [16][DS] fp16 hi/lo tiles: dgh = [dar|daz|dnt*r] (also the MFMA A operand) and dgi = [dar|daz|dnt];
-  // both are copied out as 16-byte chunks into the dGH / dGI planes (K padding columns stay zero).
-  // double-buffered by step parity (kept with the second barrier below: dropping that barrier was slower)
+                                                            int ldd, _Float16* __restrict__ dGN_hi,
+                                                            _Float16* __restrict__ dGN_lo) {
+  constexpr int DS = 32 * KSB + 8;
+  // per step parity: dgh hi | dgh lo (padded layout, also the MFMA A operand) | dgi hi | dgi lo (3H layout); columns
+  // never written (K padding, the tail of the dnr block) stay zero.  Double-buffered by step parity (kept with
+  // the second barrier below: dropping that barrier was slower)
   __shared__ __attribute__((aligned(16))) _Float16 dbuf2[2 * 4 * MB * DS];
   for (int i = threadIdx.x; i < 2 * 4 * MB * DS; i += NTHREADS) dbuf2[i] = (_Float16)0.f;
 
@@ -277,20 +281,21 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   const bool jv = j < H;
   const int jc = jv ? j : H - 1;
   const int b0 = blockIdx.x * MB;
-  const int G3 = 3 * H;
+  const int MS = 8 * ((2 * H + 7) / 8), HN = 8 * ((H + 7) / 8);
   const float s_in = scales ? scales[0] : 1.f;
   // fused MSE (wgnn_bwd_mse_part): dY is not materialised, dY[b,t] = (Y[b,t] - L[b,t]) * scales[2] is formed here;
   // Y[b,t] is the h_prev this kernel loaded for step t+1, so only L is read in dY's place.
   const float coef = Lab ? scales[2] : 1.f;
 
-  Frag WT[KS3];                                    // B operand: W_hh[k][j], k = 32ks + 8g + jj (gate row)
+  Frag WT[KSB];                                    // B operand: W_hh[row(k)][j], k = 32ks + 8g + jj in the padded layout
 #pragma unroll
-  for (int ks = 0; ks < KS3; ++ks) {
+  for (int ks = 0; ks < KSB; ++ks) {
     float x[8];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const int k = 32 * ks + 8 * g + jj;
-      x[jj] = (jv && k < G3) ? Whh[(size_t)k * H + j] : 0.f;
+      const int row = k < 2 * H ? k : ((k >= MS && k - MS < H) ? 2 * H + (k - MS) : -1);
+      x[jj] = (jv && row >= 0) ? Whh[(size_t)row * H + j] : 0.f;
     }
     WT[ks] = split_vals(x);
   }
@@ -304,6 +309,39 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     const int m = 4 * g + r;
     rowok[r] = jv && b0 + m < B;
     rowt[r] = (b0 + m < B ? m : B - 1 - b0) * T;
+  }
+  // ---- copy-out plan, fixed for the whole launch: per step the workgroup moves, as 16-byte chunks,
+  // 2 planes x 16 rows x ldd/8 chunks of the dgi tile and 2 planes x 16 rows x HN/8 chunks of the dnr block.
+  // Chunk q = threadIdx.x + 512 i: its LDS offset, destination and row stride never change (only t does).
+  constexpr int NCH = (2 * MB * (4 * KSB) + 2 * MB * (4 * KSB) / 2 + NTHREADS - 1) / NTHREADS;   // upper bound
+  int c_lds[NCH], c_step[NCH];
+  _Float16* c_dst[NCH];
+  {
+    const int cpr = ldd / 8, cpn = HN / 8;
+    const int n_i = 2 * MB * cpr, n_n = 2 * MB * cpn;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int q = threadIdx.x + NTHREADS * i;
+      c_dst[i] = nullptr;
+      c_lds[i] = 0;
+      c_step[i] = 0;
+      if (q < n_i) {
+        const int plane = q / (MB * cpr), rem = q % (MB * cpr), m = rem / cpr, ch = rem % cpr;
+        if (b0 + m < B && (X3 || plane == 0)) {
+          c_lds[i] = (2 + plane) * MB * DS + m * DS + 8 * ch;
+          c_dst[i] = (plane ? dGI_lo : dGI_hi) + ((size_t)(b0 + m) * T) * ldd + 8 * ch;
+          c_step[i] = ldd;
+        }
+      } else if (q - n_i < n_n) {
+        q -= n_i;
+        const int plane = q / (MB * cpn), rem = q % (MB * cpn), m = rem / cpn, ch = rem % cpn;
+        if (b0 + m < B && (X3 || plane == 0)) {
+          c_lds[i] = plane * MB * DS + m * DS + MS + 8 * ch;
+          c_dst[i] = (plane ? dGN_lo : dGN_hi) + ((size_t)(b0 + m) * T) * HN + 8 * ch;
+          c_step[i] = HN;
+        }
+      }
+    }
   }
   struct StepIn { float dy[4], r[4], z[4], n[4], ghn[4], hp[4]; };
   auto load_step = [&](int t, StepIn& s) {
@@ -357,7 +395,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
         if (jv) {
           put_split<X3>(dhi, dlo, m * DS + j, dar);
           put_split<X3>(dhi, dlo, m * DS + H + j, daz);
-          put_split<X3>(dhi, dlo, m * DS + 2 * H + j, dnr);
+          put_split<X3>(dhi, dlo, m * DS + MS + j, dnr);
           ihi[m * DS + j] = dhi[m * DS + j];
           ihi[m * DS + H + j] = dhi[m * DS + H + j];
           if (X3) {
@@ -369,22 +407,16 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
       }
     }
     __syncthreads();
-    {  // planes out: rows (b, t) of dGH and dGI, ldd/8 chunks of 16 B per row and plane
-      const int cpr = ldd / 8;
-      for (int q = threadIdx.x; q < 4 * MB * cpr; q += NTHREADS) {
-        const int buf = q / (MB * cpr), rem = q % (MB * cpr);
-        const int m = rem / cpr, ch = rem % cpr;
-        const int b = b0 + m;
-        if (b < B && (X3 || (buf & 1) == 0)) {        // f16 mode: hi planes only
-          const h8 v = *(const h8*)(dbuf + buf * MB * DS + m * DS + 8 * ch);
-          _Float16* dst = buf == 0 ? dGH_hi : (buf == 1 ? dGH_lo : (buf == 2 ? dGI_hi : dGI_lo));
-          *(h8*)(dst + (size_t)b0 * T * ldd + (m * T + t) * ldd + 8 * ch) = v;
-        }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {   // planes out: rows (b, t) of dGI and of dGHn
+      if (c_dst[i]) {
+        const h8 v = *(const h8*)(dbuf + c_lds[i]);
+        *(h8*)(c_dst[i] + (size_t)t * c_step[i]) = v;
       }
     }
     if (active && t > 0) {
 #pragma unroll
-      for (int ks = 0; ks < KS3; ++ks) {
+      for (int ks = 0; ks < KSB; ++ks) {
         Frag a;
         a.hi = *(const h8*)(dhi + c * DS + 32 * ks + 8 * g);
         if (X3) a.lo = *(const h8*)(dlo + c * DS + 32 * ks + 8 * g);
@@ -437,27 +469,31 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
   return WGNN_OK;
 }
 
+int grux_hn(int H) { return 8 * cdiv_i(H, 8); }
+int grux_msplit(int H) { return 8 * cdiv_i(2 * H, 8); }
+
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
                     const float* gates,
-                    const float* scales, void* dGI_planes, void* dGH_planes, int ldd, bool x3, hipStream_t st) {
+                    const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st) {
   _Float16* ih = (_Float16*)dGI_planes;
   _Float16* il = ih + (size_t)B * T * ldd;
-  _Float16* hh = (_Float16*)dGH_planes;
-  _Float16* hl = hh + (size_t)B * T * ldd;
-  if (ldd % 8 != 0 || ldd > 32 * cdiv_i(3 * H, 32)) return WGNN_ERR_SHAPE;
+  _Float16* nh = (_Float16*)dGHn_planes;
+  _Float16* nl = nh + (size_t)B * T * grux_hn(H);
+  const int ksb = cdiv_i(grux_msplit(H) + H, 32);
+  if (ldd % 8 != 0 || ldd < 3 * H || ldd > 32 * ksb) return WGNN_ERR_SHAPE;
   const double bt = (double)B * T;
-  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (4 * H + 2 * H + 6 * H);
+  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (4 * H + 2 * H + 3 * H + H);
   const dim3 grid(cdiv_i(B, MB));
 #define BCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
     PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                             \
                 hipLaunchKernelGGL((grux_bwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
-                                   gates, scales, ih, il, hh, hl, ldd));                                                  \
+                                   gates, scales, ih, il, ldd, nh, nl));                                                  \
   else                                                                                                             \
     PROF_LAUNCH("grux_bwd_kernel<" #K ",f16>", fl, by * 0.75, st,                                                  \
                 hipLaunchKernelGGL((grux_bwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
-                                   gates, scales, ih, il, hh, hl, ldd))
-  switch (cdiv_i(3 * H, 32)) {
+                                   gates, scales, ih, il, ldd, nh, nl))
+  switch (ksb) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;
     case 3: BCASE(3); break;

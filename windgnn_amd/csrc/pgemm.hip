@@ -202,14 +202,19 @@ __device__ __forceinline__ int tn_g(int stride32, int r) {   // stride32 = row b
   return u == 0 ? (r & 7) : (u == 4 ? ((r >> 1) & 3) : ((r >> 2) & 1));
 }
 
-template <int T, bool X3>
+// A2 (template flag): the A operand's columns m >= msplit come from a second pair of planes, column m - msplit of
+// A2hi / A2lo (row stride lda2); msplit is a multiple of 8 so no 16-byte chunk straddles the two sources.  Used for
+// dW_hh = [dGI_r | dGI_z | dGH_n]^T Hprev: the BPTT kernel stores the n third of dGH only (its r and z thirds equal dGI's).
+template <int T, bool X3, bool A2>
 __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16* __restrict__ Ahi,
                                                                 const _Float16* __restrict__ Alo, int lda,
                                                                 const _Float16* __restrict__ Bhi,
                                                                 const _Float16* __restrict__ Blo, int ldb,
                                                                 int shift_T, int K, int kchunk,
                                                                 float* __restrict__ partial, int Mout, int Nout,
-                                                                int nNb) {
+                                                                int nNb, const _Float16* __restrict__ A2hi,
+                                                                const _Float16* __restrict__ A2lo, int lda2,
+                                                                int msplit) {
   constexpr int BM = TN_BM, BN = 32 * T;
   constexpr int ARB = BM * 2, BRB = BN * 2;                         // row bytes
   constexpr int A_PL = 32 * ARB, B_PL = 32 * BRB, STAGE = 2 * A_PL + 2 * B_PL;
@@ -252,6 +257,11 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
       ld[it] = lda;
       prow[it] = row;
       pcol[it] = col < lda ? col : 0;                              // columns past the planes: any finite data
+      if (A2 && col >= msplit) {
+        base[it] = plane ? A2lo : A2hi;
+        ld[it] = lda2;
+        pcol[it] = col - msplit < lda2 ? col - msplit : 0;
+      }
       dst[it] = plane * A_PL + (pp % AP) * 1024;
     } else {
       const int q2 = pp - PL * AP;
@@ -358,7 +368,9 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
 __global__ void tn_reduce_kernel(const float* __restrict__ partial, int splitk, int T, int nNb, int ntiles, int Mout,
                                  int Nout, float* __restrict__ C, int ldc, int ncols_main,
                                  float* __restrict__ bias_out, const float* __restrict__ scales,
-                                 unsigned* status) {
+                                 unsigned* status, int msplit, int rows1) {
+  // msplit > 0: GEMM row m < rows1 is output row m, GEMM row m >= msplit is output row rows1 + (m - msplit),
+  // rows in between are padding (the two-source A operand of pgemm_tn_kernel<.., A2 = true>)
   const size_t slab4 = (size_t)ntiles * TN_WAVES * 5 * T * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 quads x 4 z phases per block
   const size_t q = (size_t)blockIdx.x * 64 + tx;                     // slab4 is a multiple of 64
@@ -391,7 +403,11 @@ __global__ void tn_reduce_kernel(const float* __restrict__ partial, int splitk, 
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int m = m0 + r;
+    int m = m0 + r;
+    if (msplit > 0) {
+      if (m >= msplit) m = rows1 + (m - msplit);
+      else if (m >= rows1) continue;
+    }
     if (m >= Mout) continue;
     bad |= !(__builtin_fabsf(s[r]) <= 3.0e38f);                      // inf / NaN in a final gradient
     if (n < ncols_main) C[(size_t)m * ldc + n] = s[r];
@@ -541,27 +557,38 @@ int pgemm_tn_tiles(int Mout, int Nout) {
 
 template <int T>
 static int launch_tn_t(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
-                       int K, int splitk, float* partial, int Mout, int Nout, bool x3, int nNb, hipStream_t st) {
+                       int K, int splitk, float* partial, int Mout, int Nout, bool x3, int nNb, const void* A2hi,
+                       const void* A2lo, int lda2, int msplit, hipStream_t st) {
   const int nMb = cdiv_i(Mout, TN_BM);
   const int kchunk = cdiv_i(cdiv_i(K, splitk), 32) * 32;
   const size_t smem = 2 * (size_t)(2 * 32 * 2 * (TN_BM + 32 * T));
-  static std::atomic<unsigned long long> done{0}, done16{0};
-  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
+  static std::atomic<unsigned long long> done{0}, done16{0}, done2{0}, done216{0};
+  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, true, false>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, false, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
   const double fl = 2.0 * Mout * (double)Nout * K;
   const double by = (x3 ? 4.0 : 2.0) * ((double)K * Mout + (double)K * Nout) + 4.0 * (double)splitk * Mout * Nout;
   static const std::string name = "pgemm_tn_kernel<" + std::to_string(T) + ">",
                            name16 = "pgemm_tn_kernel<" + std::to_string(T) + ",f16>";
-  if (x3)
-    PROF_LAUNCH(name.c_str(), fl, by, st,
-                hipLaunchKernelGGL((pgemm_tn_kernel<T, true>), dim3(splitk, nMb * nNb), dim3(64 * TN_WAVES), smem, st,
-                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
-                                   (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
-  else
-    PROF_LAUNCH(name16.c_str(), fl, by, st,
-                hipLaunchKernelGGL((pgemm_tn_kernel<T, false>), dim3(splitk, nMb * nNb), dim3(64 * TN_WAVES), smem, st,
-                                   (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi,
-                                   (const _Float16*)Blo, ldb, shift_T, K, kchunk, partial, Mout, Nout, nNb));
+  const dim3 grid(splitk, nMb * nNb), block(64 * TN_WAVES);
+#define TN_ARGS (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi, (const _Float16*)Blo, ldb, shift_T, K, \
+                kchunk, partial, Mout, Nout, nNb, (const _Float16*)A2hi, (const _Float16*)A2lo, lda2, msplit
+  if (A2hi) {
+    if constexpr (T <= 4) {     // only the narrow dW_hh product has a two-source A operand
+      if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, true, true>, smem, done2) != WGNN_OK) return WGNN_ERR_HIP;
+      if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, false, true>, smem, done216) != WGNN_OK) return WGNN_ERR_HIP;
+      if (x3)
+        PROF_LAUNCH(name.c_str(), fl, by, st, hipLaunchKernelGGL((pgemm_tn_kernel<T, true, true>), grid, block, smem, st, TN_ARGS));
+      else
+        PROF_LAUNCH(name16.c_str(), fl, by, st, hipLaunchKernelGGL((pgemm_tn_kernel<T, false, true>), grid, block, smem, st, TN_ARGS));
+    } else {
+      return WGNN_ERR_UNSUPPORTED;
+    }
+  } else if (x3) {
+    PROF_LAUNCH(name.c_str(), fl, by, st, hipLaunchKernelGGL((pgemm_tn_kernel<T, true, false>), grid, block, smem, st, TN_ARGS));
+  } else {
+    PROF_LAUNCH(name16.c_str(), fl, by, st, hipLaunchKernelGGL((pgemm_tn_kernel<T, false, false>), grid, block, smem, st, TN_ARGS));
+  }
+#undef TN_ARGS
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -574,14 +601,17 @@ size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk) {
 
 // C[Mout][ldc] columns [0, ncols_main) and bias_out (column Nout-1) = scales[1] * sum over z of launch_pgemm_tn's partials.
 int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
-                           float* bias_out, const float* scales, unsigned* status, hipStream_t st) {
+                           float* bias_out, const float* scales, unsigned* status, int msplit, int rows1, int Mgemm,
+                           hipStream_t st) {
+  // Mout: rows of C; Mgemm: rows of the GEMM that wrote the partials (= Mout unless the A operand had two sources)
   int nNb, T;
   tn_shape(Nout, nNb, T);
-  const int ntiles = cdiv_i(Mout, TN_BM) * nNb;
+  const int ntiles = cdiv_i(Mgemm, TN_BM) * nNb;
   const size_t slab4 = (size_t)ntiles * TN_WAVES * 5 * T * 64;
   PROF_LAUNCH("tn_reduce_kernel", (double)slab4 * 4 * splitk, 16.0 * slab4 * splitk + 4.0 * Mout * Nout, st,
               hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(slab4 / 64)), dim3(256), 0, st, partial,
-                                 splitk, T, nNb, ntiles, Mout, Nout, C, ldc, ncols_main, bias_out, scales, status));
+                                 splitk, T, nNb, ntiles, Mout, Nout, C, ldc, ncols_main, bias_out, scales, status,
+                                 msplit, rows1));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -591,13 +621,16 @@ int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout,
 // shift_T > 0: B row k is taken from row k-1, and from the extra row K (which the producer fills with what the
 // operand looks like at a window start) where k % shift_T == 0.
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
-                    int K, int splitk, float* partial, int Mout, int Nout, bool x3, hipStream_t st) {
+                    int K, int splitk, float* partial, int Mout, int Nout, bool x3, const void* A2hi, const void* A2lo,
+                    int lda2, int msplit, hipStream_t st) {
   if (lda % 8 != 0 || ldb % 8 != 0 || K < 1) return WGNN_ERR_SHAPE;
+  if (A2hi && (lda2 % 8 != 0 || msplit % 8 != 0 || msplit > lda)) return WGNN_ERR_SHAPE;
   int nNb, T;
   tn_shape(Nout, nNb, T);
   switch (T) {
 #define TN_CASE(t) \
-  case t: return launch_tn_t<t>(Ahi, Alo, lda, Bhi, Blo, ldb, shift_T, K, splitk, partial, Mout, Nout, x3, nNb, st);
+  case t: return launch_tn_t<t>(Ahi, Alo, lda, Bhi, Blo, ldb, shift_T, K, splitk, partial, Mout, Nout, x3, nNb, A2hi, A2lo, \
+                                lda2, msplit, st);
     TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(7)
 #undef TN_CASE
   }
