@@ -22,7 +22,8 @@ def short(n):
         t = re.match(r"I((?:L[ib]\d+E)+)E", tail)      # <int..., bool X3>: bench.py prints X3 = false as ",f16"
         if t:
             args = re.findall(r"Li(\d+)E", t.group(1))
-            if "0" in re.findall(r"Lb(\d)E", t.group(1)):
+            flags = re.findall(r"Lb(\d)E", t.group(1))        # first bool = X3 (false: bench.py prints ",f16"); later
+            if flags and flags[0] == "0":                       # flags (e.g. the TN GEMM's two-source A) are not printed
                 args.append("f16")
             return name + ("<" + ",".join(args) + ">" if args else "")
         return name

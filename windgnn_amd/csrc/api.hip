@@ -24,7 +24,6 @@ struct Layout {
   bool dghn;                                     // fast f16x3 recurrence: only the n third of dGH is stored (dGHn planes)
   int hn, msplit, m_hh;                          // its row width, its first GEMM row, GEMM rows of the dW_hh product
   size_t st_h1;                                  // general GCN: layer-1 activations
-  size_t st_mask;                                // dense f16x3 GCN: layer-2 ReLU mask bits for the backward
   size_t st_stats;                               // wgnn_fwd_loss: MSE partial pairs (sum | max) of the forward recurrence
   size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_kp_f, ws_hc, ws_du, ws_dhz, ws_dhw, ws_hhp_b, ws_kp_b, ws_dc;   // general GRU / GCN scratch
 };
@@ -74,7 +73,6 @@ Layout make_layout(const wgnn_dims* d) {
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
   L.st_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.st_stats = o; o += al(2 * (size_t)grux_blocks(d->B));
-  L.st_mask = o; o += al(x3 && !L.gen_gcn ? gcnx_mask_floats((int)L.BT) : 0);
   L.stash_floats = o;
   L.dghn = x3 && !L.gen_gru;
   L.hn = grux_hn(d->H);
@@ -200,7 +198,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const float* X, const wg
                                p->conv2_bias, sf ? sf + L.st_h1 : ws + L.ws_h1, nullptr, g, L.Ip, full, status, st);
     else
       rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                            (int)L.Ip, full, status, sf ? sf + L.st_mask : nullptr, st);
+                            (int)L.Ip, full, status, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
@@ -363,7 +361,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
       return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
                                  L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
                                  g->conv2_weight, g->conv2_bias, st);
-    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, sf + L.st_mask, dg,
+    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                           scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, st);
     if (rc != WGNN_OK) return rc;
     return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT, d->S), g->conv1_weight, g->conv1_bias,

@@ -135,11 +135,9 @@ size_t gcnx2_bwd_partial_floats(int ntiles);
 int gcnx_bwd_grid(int ntiles, int S);
 // g_planes: fp16 hi plane [ntiles][ldg] followed by the lo plane; column S*13 holds 1.0, later columns 0
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status,
-                     void* gmask /*nullable: gcnx_mask_floats(ntiles) floats, the backward's ReLU mask bits*/, hipStream_t st);
-size_t gcnx_mask_floats(int ntiles);
+                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, hipStream_t st);
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const void* gmask, const float* dg, const float* scales,
+                     const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
                      int scale_in, float* partial, bool x3, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,

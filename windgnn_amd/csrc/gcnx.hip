@@ -181,18 +181,13 @@ __device__ __forceinline__ Frag xfrag_nat(const float* xb, int i, int c, int g) 
 }
 
 constexpr int FWD_WAVES = 8;   // waves per forward block (A fragments are shared through LDS)
-// ReLU mask of layer 2 for the backward: 2 x 64-bit words per 128 tile elements (even / odd element of lane p's pair),
-// 16 words = 128 bytes per tile (up to 1024 elements: S <= 64).  56 bytes of information replace the 896-byte fp16
-// plane row the backward used to read for the sign, and `g > 0` is now exact (a g below fp16's 6e-8 has hi = 0).
-constexpr int MASK_WORDS = 16;
 
 template <int NT, bool X3>
 __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const float* __restrict__ b2, _Float16* __restrict__ ghi,
-                                                       _Float16* __restrict__ glo, int ldp, unsigned* status,
-                                                       unsigned long long* __restrict__ gmask) {
+                                                       _Float16* __restrict__ glo, int ldp, unsigned* status) {
   constexpr int KS = (NT + 1) / 2;
   constexpr int SP = 16 * NT;
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
@@ -322,14 +317,6 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
         if (64 * k < ldp / 2) {
           const int p = lane + 64 * k, e = 2 * p;
           float v0 = ob[map.o0[k]], v1 = ob[map.o1[k]];          // dump slot for e >= I: value unused
-          if (gmask) {   // ReLU mask of the backward, exact (g > 0 in fp32): bit `lane` of word 2k / 2k+1 = element 2p / 2p+1
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(e < I && v0 > 0.f);
-            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(e + 1 < I && v1 > 0.f);
-            if (lane == 0) {
-              gmask[(size_t)tile * MASK_WORDS + 2 * k] = m0;
-              gmask[(size_t)tile * MASK_WORDS + 2 * k + 1] = m1;
-            }
-          }
           v0 = e < I ? v0 : (e == I ? 1.f : 0.f);
           v1 = e + 1 < I ? v1 : (e + 1 == I ? 1.f : 0.f);
           h2 hi, lo;
@@ -366,7 +353,7 @@ template <int NT, bool X3>
 __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const float* __restrict__ X, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
-                                                       const unsigned long long* __restrict__ gmask,
+                                                       const _Float16* __restrict__ gact, int ld_g,
                                                        const float* __restrict__ dg, const float* __restrict__ scales,
                                                        int scale_in, float* __restrict__ partial) {
   constexpr int KS = (NT + 1) / 2;
@@ -443,24 +430,10 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
   float db1acc = 0.f, db2acc = 0.f;
 
   f32x2 xr[NP], dr[NP];
-  unsigned long long mk[2 * NP];     // the tile's ReLU mask words (every lane loads the same 16 bytes)
-  auto load_mask = [&](int tile) {
-    const unsigned long long* mrow = gmask + (size_t)tile * MASK_WORDS;
-#pragma unroll
-    for (int k = 0; k < 2 * NP; ++k) mk[k] = (128 * (k / 2) < I) ? mrow[k] : 0ull;
-  };
-  // x where this lane's bit of the (wave-uniform) mask word is set, else 0: the word goes to an SGPR pair and is
-  // the condition operand of one v_cndmask
-  auto sel = [&](unsigned long long m, float x) {
-    const unsigned long long ms = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(m >> 32)) << 32) |
-                                  (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)m);
-    float r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(ms));
-    return r;
-  };
+  h2 gr[NP];
   if (wave_id < ntiles) {
     gload_pairs<NP>(xr, X + (size_t)wave_id * I, lane, I);
-    load_mask(wave_id);
+    gload_pairs_h<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
     gload_pairs<NP>(dr, dg + (size_t)wave_id * I, lane, I);
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
@@ -471,15 +444,15 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
       if (64 * k < npairs) {       // wave-uniform; lanes past the tile write the dump slot
         xb[map.o0[k]] = xr[k][0];
         xb[map.o1[k]] = xr[k][1];
-        db[map.o0[k]] = sel(mk[2 * k], dr[k][0] * s_in);     // dZ2 = dg * (g > 0), range-scaled
-        db[map.o1[k]] = sel(mk[2 * k + 1], dr[k][1] * s_in);
+        db[map.o0[k]] = (float)gr[k][0] > 0.f ? dr[k][0] * s_in : 0.f;     // dZ2 = dg * (g > 0), range-scaled
+        db[map.o1[k]] = (float)gr[k][1] > 0.f ? dr[k][1] * s_in : 0.f;
       }
     }
     wave_lds_fence();
     if (tile + nwaves < ntiles) {                               // prefetch the next tile under this one's math
       const size_t nt = (size_t)(tile + nwaves);
       gload_pairs<NP>(xr, X + nt * I, lane, I);
-      load_mask(tile + nwaves);
+      gload_pairs_h<NP>(gr, gact + nt * ld_g, lane, I);
       gload_pairs<NP>(dr, dg + nt * I, lane, I);
     }
     // ---- recompute U1, H1 [s][f]
@@ -610,13 +583,11 @@ int grid_x(int ntiles, int S) {
 }  // namespace
 
 size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)256 * PART; }
-size_t gcnx_mask_floats(int ntiles) { return (size_t)ntiles * MASK_WORDS * 2; }
 int gcnx_bwd_grid(int ntiles, int S) { return grid_x(ntiles, S); }
 
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status,
-                     void* gmask, hipStream_t st) {
-  unsigned long long* gm = (unsigned long long*)gmask;
+                     hipStream_t st) {
   _Float16* ghi = (_Float16*)g_planes;
   _Float16* glo = ghi + (size_t)ntiles * ldg;
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
@@ -628,11 +599,11 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const fl
   if (x3)                                                                                                         \
     PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                           \
                 hipLaunchKernelGGL((gcnx_fwd_kernel<NT, true>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, b2, \
-                                   ghi, glo, ldg, status, gm));                                                   \
+                                   ghi, glo, ldg, status));                                                       \
   else                                                                                                            \
     PROF_LAUNCH("gcnx_fwd_kernel<" #NT ",f16>", fl, by * 0.75, st,                                                \
                 hipLaunchKernelGGL((gcnx_fwd_kernel<NT, false>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, \
-                                   b2, ghi, glo, ldg, status, gm))
+                                   b2, ghi, glo, ldg, status))
   switch ((S + 15) / 16) {
     case 1: FWD_CASE(1); break;
     case 2: FWD_CASE(2); break;
@@ -646,22 +617,22 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const fl
 }
 
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const void* gmask, const float* dg, const float* scales,
+                     const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
                      int scale_in, float* partial, bool x3, hipStream_t st) {
-  const unsigned long long* g = (const unsigned long long*)gmask;   // ReLU mask bits written by launch_gcnx2_fwd
+  const _Float16* g = (const _Float16*)g_planes;   // hi plane carries the sign: g > 0 <=> hi > 0
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
-  // what the launch reads: X and dg as fp32, and the layer-2 ReLU mask (2 x 8 bytes per 128 elements)
-  const double by = (double)ntiles * (S * 13 * 4.0 * 2.0 + 16.0 * cdiv_i(S * 13, 128));
+  // what the launch reads: X and dg as fp32, and the fp16 hi plane of g (2 bytes x ldg per tile) as the ReLU mask
+  const double by = (double)ntiles * (S * 13 * 4.0 * 2.0 + ldg * 2.0);
   const dim3 grid(grid_x(ntiles, S));
 #define BWD_CASE(NT)                                                                                               \
   if (x3)                                                                                                          \
     PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                            \
                 hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, W1, b1, W2, g,  \
-                                   dg, scales, scale_in, partial));                                                \
+                                   ldg, dg, scales, scale_in, partial));                                           \
   else                                                                                                             \
     PROF_LAUNCH("gcnx_bwd_kernel<" #NT ",f16>", fl, by, st,                                                        \
                 hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, W1, b1, W2, g, \
-                                   dg, scales, scale_in, partial))
+                                   ldg, dg, scales, scale_in, partial))
   switch ((S + 15) / 16) {
     case 1: BWD_CASE(1); break;
     case 2: BWD_CASE(2); break;
