@@ -69,7 +69,10 @@ Layout make_layout(const wgnn_dims* d) {
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
-  L.st_gates = o; o += al(L.BT * 4 * L.H);
+  {  // r, z, n, gh_n of every step: [B*T][4H] fp32, or the register-resident recurrences' own record layout
+    const size_t plain = L.BT * 4 * L.H, rec = (x3 && !L.gen_gru) ? grux_gates_floats(d->B, d->T, d->H) : 0;
+    L.st_gates = o; o += al(plain > rec ? plain : rec);
+  }
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
   L.st_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.st_stats = o; o += al(2 * (size_t)grux_blocks(d->B));

@@ -105,6 +105,7 @@ int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=
 // split-fp16 GRU recurrences with register-resident weights (grux.hip)
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
+size_t grux_gates_floats(int B, int T, int H);   // gate stash of the register-resident recurrences (their own layout)
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
                     float* gates, void* y_planes, bool x3, unsigned* status, const float* labels, float* stat_part,
                     hipStream_t st);

@@ -19,6 +19,7 @@ namespace {
 
 constexpr int MB = 16;
 constexpr int NTHREADS = 512;
+constexpr int GREC = 4;   // 16-byte components of a gate-stash record: r | z | n | gh_n
 
 struct Frag { h8 hi, lo; };
 
@@ -122,7 +123,14 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   // offsets.  Row indices are clamped so every load is unconditional.
   const float* GIw = GI + (size_t)b0 * T * ldgi;
   float* Yw = Y + (size_t)b0 * T * H;
-  float* gatesw = gates ? gates + (size_t)b0 * T * 4 * H : nullptr;
+  // gate stash in this kernel's own register layout, [workgroup][t][wave][r | z | n | gh_n][lane] x float4 (the 4 window
+  // rows a lane owns): one 16-byte store per lane and component (a full 1 KB per wave-instruction) instead of sixteen
+  // 4-byte stores in 64-byte segments; the BPTT kernel (same thread <-> (rows, unit) map) reads it back the same way.
+  // All four stay fp32: packing r and z as unorm16 (12 bytes per record: forward -4 us, BPTT -11 us) was tried and is
+  // WRONG for trained weights -- saturated gates need r (1 - r) to fp32's own precision (8 % gradient error on the
+  // wind_gnn_7.pth fixture).
+  const int NW = (H + 15) / 16;
+  f32x4* gatesw = gates ? (f32x4*)gates + ((size_t)blockIdx.x * T * NW + wave) * GREC * 64 + lane : nullptr;
   int rowt[4];            // (local window row) * T, clamped to the last valid window
   bool rowok[4];
 #pragma unroll
@@ -177,11 +185,13 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         az = mfma3<X3>(a, WB[1][ks], az);
         an = mfma3<X3>(a, WB[2][ks], an);
       }
+      f32x4 rg4, zg4, ng4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float rg = sigmoid_fast(ar[r]);
         const float zg = sigmoid_fast(az[r]);
         const float ng = tanh_fast(gi[2][r] + rg * an[r]);
+        rg4[r] = rg; zg4[r] = zg; ng4[r] = ng;
         hnew[r] = (1.f - zg) * ng + zg * hold[r];
         if (rowok[r]) {
           const int bt = rowt[r] + t;
@@ -191,15 +201,15 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
             ssum = fmaf(dl, dl, ssum);
             smax = fmaxf(smax, fabsf(dl));
           }
-          if (gates) {
-            const int o = bt * 4 * H + j;
-            gatesw[o] = rg;
-            gatesw[o + H] = zg;
-            gatesw[o + 2 * H] = ng;
-            gatesw[o + 3 * H] = an[r];
-          }
         }
         hold[r] = hnew[r];
+      }
+      if (gates) {
+        f32x4* rec = gatesw + (size_t)t * NW * GREC * 64;
+        rec[0] = rg4;
+        rec[64] = zg4;
+        rec[128] = ng4;
+        rec[192] = an;
       }
     }
     if (active && jv) {
@@ -299,7 +309,8 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     }
     WT[ks] = split_vals(x);
   }
-  const float* gatesw = gates + (size_t)b0 * T * 4 * H;     // workgroup-uniform bases + 32-bit lane offsets
+  const int NW = (H + 15) / 16;                              // gate stash: grux_fwd_kernel's register layout
+  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * GREC * 64 + lane;
   const float* dYw = (Lab ? Lab : dY) + (size_t)b0 * T * H;
   const float* Yw = Y + (size_t)b0 * T * H;
   int rowt[4];
@@ -346,15 +357,16 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   struct StepIn { float dy[4], r[4], z[4], n[4], ghn[4], hp[4]; };
   auto load_step = [&](int t, StepIn& s) {
     const int tc = t > 0 ? t : 0;
+    const f32x4* rec = gatesw + (size_t)tc * NW * GREC * 64;
+    const f32x4 r4 = rec[0], z4 = rec[64], n4 = rec[128], g4 = rec[192];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int bt = rowt[r] + tc;
-      const int o = bt * 4 * H + jc;
       s.dy[r] = dYw[bt * H + jc];
-      s.r[r] = gatesw[o];
-      s.z[r] = gatesw[o + H];
-      s.n[r] = gatesw[o + 2 * H];
-      s.ghn[r] = gatesw[o + 3 * H];
+      s.r[r] = r4[r];
+      s.z[r] = z4[r];
+      s.n[r] = n4[r];
+      s.ghn[r] = g4[r];
       const float hp = Yw[(bt - (tc > 0 ? 1 : 0)) * H + jc];
       s.hp[r] = tc > 0 ? hp : 0.f;
     }
@@ -437,6 +449,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 bool grux_shape_supported(int H) { return H >= 1 && H <= 127; }
 
 int grux_hp(int H) { return 32 * cdiv_i(H + 1, 32); }
+size_t grux_gates_floats(int B, int T, int H) { return (size_t)cdiv_i(B, MB) * T * cdiv_i(H, 16) * GREC * 64 * 4; }
 int grux_blocks(int B) { return cdiv_i(B, MB); }
 
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
@@ -446,7 +459,8 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
   _Float16* yh = (_Float16*)y_planes;
   _Float16* yl = yh ? yh + ((size_t)B * T + 1) * grux_hp(H) : nullptr;   // each plane has B*T + 1 rows
   const double bt = (double)B * T;
-  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0) + (labels ? H : 0));
+  const double fl = bt * 2.0 * 3 * H * H,
+               by = bt * 4.0 * (3 * H + H + (labels ? H : 0)) + (gates ? 4.0 * grux_gates_floats(B, T, H) : 0.0);
   const dim3 grid(cdiv_i(B, MB));
 #define FCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
@@ -482,7 +496,7 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const
   const int ksb = cdiv_i(grux_msplit(H) + H, 32);
   if (ldd % 8 != 0 || ldd < 3 * H || ldd > 32 * ksb) return WGNN_ERR_SHAPE;
   const double bt = (double)B * T;
-  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (4 * H + 2 * H + 3 * H + H);
+  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (2 * H + 3 * H + H) + 4.0 * grux_gates_floats(B, T, H);
   const dim3 grid(cdiv_i(B, MB));
 #define BCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
