@@ -58,7 +58,7 @@ def measure_traffic_live(args):
     tmp = tempfile.mkdtemp(prefix="wgnn_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--traffic-child", "--steps", "3", "--warmup", "1",
-             "--math", args.math, "--workload", args.workload] + (["--batch", str(args.batch)] if args.batch else [])
+             "--math", args.math, "--workload", args.workload, "--io", args.io] + (["--batch", str(args.batch)] if args.batch else [])
     try:
         for counter, sub in (("FETCH_SIZE", "F"), ("WRITE_SIZE", "W")):
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d",
@@ -79,11 +79,14 @@ def adjacency_34():
     return torch.from_numpy(z["A34"]).float()          # src/main.py:26: float64 -> .float()
 
 
-def make_inputs(B, rank, dev, S=S, H=H):
+IO_DTYPES = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+def make_inputs(B, rank, dev, S=S, H=H, io="fp32"):
     g = torch.Generator().manual_seed(1234 + rank)
     X = torch.rand(B, T, S, F, generator=g)
     L = torch.rand(B, T, H, generator=g)
-    return X.to(dev), L.to(dev)
+    return X.to(IO_DTYPES[io]).to(dev), L.to(IO_DTYPES[io]).to(dev)
 
 
 def adjacency_knn(S, k=8):
@@ -171,6 +174,8 @@ def main():
     ap.add_argument("--math", default="f16x3", choices=["f32", "f16x3", "f16"])
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
                     help="c3: 34 stations, the headline config; c5: 4096-station k-NN CSR stress config")
+    ap.add_argument("--io", default="fp32", choices=["fp32", "fp16", "bf16"],
+                    help="element type of X, Y and the labels on the wire (16-bit: BASELINE configs[2]; needs --math f16x3|f16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes (N = 1 only)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-fp32 secondary measurement")
@@ -196,7 +201,8 @@ def main():
             traffic, traffic_src = measure_traffic_live(args)
         if not traffic:
             why = traffic_src
-            traffic, traffic_src = ({}, None) if args.workload != "c3" or args.math != "f16x3" else committed_traffic()
+            traffic, traffic_src = (({}, None) if args.workload != "c3" or args.math != "f16x3" or args.io != "fp32"
+                                    else committed_traffic())
             if traffic_src:
                 traffic_src = "committed file %s (%s)" % (traffic_src, why or "--no-traffic")
 
@@ -215,7 +221,8 @@ def main():
     model = GCN_GRU(F, F, F, S * F, H, math=args.math).to(dev)
     trainer = TrainStep(model)
     A = (adjacency_34() if args.workload == "c3" else adjacency_knn(S)).to(dev)
-    X, L = make_inputs(B, rank, dev, S, H)
+    X, L = make_inputs(B, rank, dev, S, H, args.io)
+    esz = 4.0 if args.io == "fp32" else 2.0
 
     def barrier():
         if world > 1:
@@ -292,7 +299,7 @@ def main():
             mfma = {"kernel": gk["name"], "algorithmic_TFLOPs": round(tf, 1), "issued_TFLOPs": round(tf * passes, 1),
                     "peak": peak_k, "frac_issued": round(tf * passes / peak_k, 4)}
         # ---- the path as a whole: 2X + 2Y + L per window, fwd + bwd with recompute
-        alg_step = float(B) * T * (2 * S * F + 3 * H) * 4.0
+        alg_step = float(B) * T * (2 * S * F + 3 * H) * esz
         step_s = dt / args.steps
         path = {"algorithmic_bytes_per_step": round(alg_step),
                 "fwd_bwd_GBs": round(alg_step / step_s / 1e9, 1),
@@ -314,12 +321,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         fwd_s = e0.elapsed_time(e1) * 1e-3 / args.steps
-        fwd_bytes = B * T * (S * F + H) * 4.0
+        fwd_bytes = B * T * (S * F + H) * esz
         forward = {"us": round(fwd_s * 1e6, 1), "algorithmic_GBs": round(fwd_bytes / fwd_s / 1e9, 1),
                    "hbm_frac": round(fwd_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
                    "windows_per_s": round(B / fwd_s, 1)}
         # ---- secondary: the same workload in the exact-fp32 mode (bitwise fp32 fmaf chains, fp32 MFMA)
-        if world == 1 and args.math != "f32" and args.workload == "c3" and not args.no_secondary:
+        if world == 1 and args.math != "f32" and args.workload == "c3" and not args.no_secondary and args.io == "fp32":
             m32 = GCN_GRU(F, F, F, S * F, H, math="f32").to(dev)
             t32 = TrainStep(m32)
             n32 = max(5, min(args.steps, 30))
@@ -348,11 +355,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16x3": "f16x3(split-fp32)", "f16": "f16"}[args.math],
+            "dtype": {"f32": "f32", "f16x3": "f16x3(split-fp32)", "f16": "f16"}[args.math] +
+                     ("" if args.io == "fp32" else " math, %s I/O" % args.io),
             "data": "synthetic",
             "config": {"workload": "S=%d stations%s, T=24, F=13, H=%d, B=%d windows/GPU; step = forward + MSE + "
-                                   "backward + grad all-reduce (N>1) + Adam; fp32 I/O"
-                                   % (S, "" if args.workload == "c3" else " (symmetric 8-NN graph, CSR)", H, B),
+                                   "backward + grad all-reduce (N>1) + Adam; %s I/O"
+                                   % (S, "" if args.workload == "c3" else " (symmetric 8-NN graph, CSR)", H, B, args.io),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "math": args.math},
             "loss": round(float(loss), 6),
             "roofline": roofline,

@@ -80,6 +80,14 @@ typedef enum wgnn_math {
  *                   exact fp32; `math` selects the kernels of the dense GRU contractions as usual. */
 typedef enum wgnn_adj_format { WGNN_ADJ_DENSE = 0, WGNN_ADJ_CSR = 1 } wgnn_adj_format;
 
+/* Element type of the tensors "on the wire": X [B,T,S,F], Y [B,T,H] and the labels of wgnn_fwd_loss / wgnn_bwd_mse_part.
+ * WGNN_IO_F32 (default; what every other comment in this header assumes), or one of the 16-bit types for BASELINE's
+ * 16-bit configuration (half the algorithmic bytes of the path: 26 112 B per window forward instead of 52 224).
+ * Parameters, gradients, dY, the adjacency, workspace and stash are unaffected.  16-bit I/O needs the fp16-plane
+ * kernels: math F16X3 or F16, dense adjacency, H <= 127 -- anything else returns WGNN_ERR_UNSUPPORTED.  Y is the
+ * fp32 result rounded once on the way out; the loss statistics and the backward use the unrounded hidden state. */
+typedef enum wgnn_io { WGNN_IO_F32 = 0, WGNN_IO_F16 = 1, WGNN_IO_BF16 = 2 } wgnn_io;
+
 typedef struct wgnn_dims {
   int32_t B;          /* windows in this call */
   int32_t T;          /* timesteps per window (seq_len) */
@@ -89,6 +97,7 @@ typedef struct wgnn_dims {
   int32_t math;       /* wgnn_math */
   int32_t adj_format; /* wgnn_adj_format */
   int32_t nnz;        /* CSR only: stored entries of A */
+  int32_t io;         /* wgnn_io: element type of X, Y and the labels */
 } wgnn_dims;
 
 /* The 8 tensors of the reference state_dict, in its key order. */
@@ -124,7 +133,7 @@ size_t wgnn_stash_bytes(const wgnn_dims* d);
 
 /* Y[B,T,H] = GRU(relu(A relu(A X W1 + b1) W2 + b2)), h0 = 0 per window.
  * stash may be NULL (inference: src/main.py:100-102); otherwise it receives what wgnn_bwd needs. */
-int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, float* Y,
+int wgnn_fwd(const wgnn_dims* d, const float* A, const void* X /* d->io */, const wgnn_params* p, void* Y /* d->io */,
              void* stash, void* workspace, size_t workspace_bytes, void* stream);
 
 /* wgnn_fwd for a training step whose loss is nn.MSELoss()(Y, labels) (src/main.py:66 + :72): the same Y and stash,
@@ -132,14 +141,14 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
  * (Y - labels) to per-workgroup partial sums of squares and maxima inside the stash, so that
  * wgnn_bwd_mse_part(..., part | 8) needs no pass over Y and the labels for the loss and the range scale.  On every
  * other shape it is exactly wgnn_fwd (and the backward ignores bit 8).  stash must not be NULL. */
-int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* labels,
-                  float* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream);
+int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* labels,
+                  void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Gradients of sum(Y * dY) w.r.t. the 8 parameters (overwritten, not accumulated).
  * No dX and no dA: neither requires grad in the reference (src/main.py:26,
  * src/step4_sequence_preparer.py:58). */
-int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p,
-             const float* Y, const float* dY, const void* stash, const wgnn_grads* g,
+int wgnn_bwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p,
+             const void* Y, const float* dY /* always fp32 */, const void* stash, const wgnn_grads* g,
              void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same backward in parts, for callers that overlap them (no reference counterpart: it has no
@@ -150,8 +159,8 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
  * Parts 4 and 2 only read what part 1 wrote and use disjoint scratch, so after part 1 they may run
  * concurrently on two streams (ordered after part 1 by events), and a data-parallel caller can start
  * all-reducing the GRU gradients as soon as part 4 is done. */
-int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p,
-                  const float* Y, const float* dY, const void* stash, const wgnn_grads* g,
+int wgnn_bwd_part(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p,
+                  const void* Y, const float* dY, const void* stash, const wgnn_grads* g,
                   void* workspace, size_t workspace_bytes, void* stream, int part /* bit mask 1..7 */);
 
 /* The reference's loss call folded into the backward (src/main.py:72 + :79): gradients of
@@ -159,8 +168,8 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn
  * that has part bit 1).  Same parts, scratch and ordering as wgnn_bwd_part; equal to wgnn_mse_loss_grad followed by
  * wgnn_bwd_part, but dY [B,T,H] is not written or re-read where the recurrence kernel can form it from Y and the
  * labels (f16x3 / f16, H <= 127); other shapes build dY inside the workspace. */
-int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p,
-                      const float* Y, const float* labels /* [B,T,H] */, float grad_scale, float* loss,
+int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p,
+                      const void* Y, const void* labels /* [B,T,H], d->io */, float grad_scale, float* loss,
                       const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
                       void* stream, int part /* bit mask 1..7, + 8: the forward was wgnn_fwd_loss on these labels */);
 

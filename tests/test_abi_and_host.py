@@ -41,6 +41,14 @@ def test_dims_validation_no_gpu_needed():
     c5 = L.Dims(128, 24, 4096, 13, 12288, 0, 1, 73000)        # BASELINE configs[4], one GPU's shard
     assert lib.wgnn_workspace_bytes(ctypes.byref(c5)) > (1 << 32) and lib.wgnn_stash_bytes(ctypes.byref(c5)) > 0
     assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4, 24, 34, 13, 400, 1, 0, 0))) > 0   # wide GRU: general path
+    # 16-bit X / Y / labels (wgnn_io): only with the fp16-plane kernels (math f16x3 / f16, dense adjacency, H <= 127)
+    assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4, 24, 34, 13, 102, 1, 0, 0, L.IO_BF16))) > 0
+    assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4, 24, 34, 13, 102, 2, 0, 0, L.IO_F16))) > 0
+    for bad in (L.Dims(4, 24, 34, 13, 102, 0, 0, 0, L.IO_F16),       # exact-fp32 math has no 16-bit I/O
+                L.Dims(4, 24, 34, 13, 400, 1, 0, 0, L.IO_F16),       # wide GRU: general path
+                L.Dims(4, 24, 200, 13, 60, 1, 1, 1000, L.IO_BF16),   # CSR adjacency
+                L.Dims(4, 24, 34, 13, 102, 1, 0, 0, 3)):             # unknown I/O type
+        assert lib.wgnn_workspace_bytes(ctypes.byref(bad)) == 0
     p = L.Params()
     rc = lib.wgnn_fwd(ctypes.byref(ok), None, None, ctypes.byref(p), None, None, None, 0, None)
     assert rc == -1 and b"NULL" in lib.wgnn_strerror(rc)

@@ -700,3 +700,105 @@ def test_fp16_plane_modes_report_out_of_range_values_loudly(math):
     out32 = _model_from(p, 34, 102, "f32")(A.to(dev), Xbig.to(dev))
     assert max_abs(out32.detach().cpu().reshape(Yo.shape), Yo) <= Y_TOL
     check_range_status(dev)
+
+
+# ---- 16-bit I/O (wgnn_io): X, Y and the labels as fp16 / bf16 on the wire (BASELINE configs[2]: "batch 4096 bf16").
+# What is compared: the oracle in fp64 on the SAME rounded inputs.  Y is the fp32-grade (or, with math "f16", the
+# 16-bit-math) result rounded ONCE to the I/O type, so its tolerance is the math mode's plus half an ulp of the I/O
+# type at |Y| < 1: fp16 2^-12 = 2.5e-4, bf16 2^-9 = 2.0e-3.  The loss statistics and the backward use the unrounded
+# hidden state (h planes of the stash), so gradients keep the math mode's own tolerance.
+IO_ROUND = {torch.float16: 2.5e-4, torch.bfloat16: 2.0e-3}
+
+
+@pytest.mark.parametrize("iodt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("math", ["f16x3", "f16"])
+@pytest.mark.parametrize("S,T,B,H", [(34, 24, 37, 102), (7, 12, 5, 21), (3, 2, 1, 9)])
+def test_16bit_io_against_oracle_on_the_rounded_inputs(S, T, B, H, math, iodt):
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.functional import gcn_gru_backward_mse_raw, gcn_gru_backward_raw, gcn_gru_forward_raw
+    dev = _dev()
+    g = torch.Generator().manual_seed(160 + S + H)
+    A = torch.rand(S, S, generator=g) / S + 0.01
+    X = torch.rand(B, T, S, 13, generator=g).to(iodt)            # what travels: already rounded
+    L = torch.rand(B, T, H, generator=g).to(iodt)
+    p = orc.init_params(S, 13, H, seed=S)
+    Yo, loss_o, go = _oracle_step(A, X.float(), L.float(), p)
+    model = _model_from(p, S, H, math)
+    params = [q.detach() for q in model.hot_path_parameters()]
+    y_tol = (Y_TOL if math == "f16x3" else F16_Y_TOL) + IO_ROUND[iodt]
+    g_tol = G_TOL if math == "f16x3" else F16_G_TOL
+    Y, stash, d = gcn_gru_forward_raw(A.to(dev), X.to(dev), params, model.math, want_stash=True, labels=L.to(dev))
+    assert Y.dtype == iodt and d.io == {torch.float16: 1, torch.bfloat16: 2}[iodt]
+    assert max_abs(Y.float().cpu(), Yo) <= y_tol
+    grads = [torch.empty_like(q) for q in params]
+    loss = torch.empty((), device=dev)
+    gcn_gru_backward_mse_raw(d, A.to(dev), X.to(dev), params, Y, L.to(dev), stash, grads, loss, 1.0, part=7 | 8)
+    assert abs(float(loss) - float(loss_o)) <= (2e-3 if math == "f16" else 1e-5) * max(1.0, float(loss_o))
+    for key, gf in zip(PARAM_KEYS, grads):
+        assert rel_to_max(gf.cpu(), go[key]) <= g_tol, key
+    # explicit fp32 dY (wgnn_bwd): same gradients as the fused-loss route up to the rounding of dY's own formation
+    dY = (2.0 * (Yo - L.double()) / Yo.numel()).float().to(dev)
+    grads2 = [torch.empty_like(q) for q in params]
+    gcn_gru_backward_raw(d, A.to(dev), X.to(dev), params, Y, dY, stash, grads2)
+    for key, gf in zip(PARAM_KEYS, grads2):
+        assert rel_to_max(gf.cpu(), go[key]) <= g_tol, key
+    # inference (no stash) and the nn.Module: the output comes back in the input's type, autograd works
+    with torch.no_grad():
+        out = model(A.to(dev), X.to(dev))
+    assert out.dtype == iodt and max_abs(out.float().cpu().reshape(Yo.shape), Yo) <= y_tol
+    model.zero_grad()
+    out = model(A.to(dev), X.to(dev))
+    (out.float() * dY.reshape(out.shape)).sum().backward()
+    for key, q in model.named_parameters():
+        assert rel_to_max(q.grad.cpu(), go[key]) <= g_tol, key
+    with pytest.raises(RuntimeError):                      # exact-fp32 math has no 16-bit I/O: refused, not converted
+        _model_from(p, S, H, "f32")(A.to(dev), X.to(dev))
+
+
+@pytest.mark.parametrize("math,iodt", [("f16", torch.bfloat16), ("f16x3", torch.float16)])
+def test_full_size_B4096_with_16bit_io(math, iodt):
+    """BASELINE configs[2] literally (S=34, T=24, B=4096, 16-bit math AND bf16 on the wire) and the fp32-grade math
+    with fp16 I/O: window independence bit for bit, exact linearity in the loss scale, and a 256-window slice
+    (Y and all 8 gradients) against the fp64 oracle on the same rounded inputs."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.functional import gcn_gru_backward_mse_raw, gcn_gru_forward_raw
+    import os
+    from conftest import GOLDEN
+    dev = _dev()
+    S, T, B, H = 34, 24, 4096, 102
+    A = torch.from_numpy(np.load(os.path.join(GOLDEN, "graph_7_34.npz"))["A34"]).float()
+    g = torch.Generator().manual_seed(299)
+    X = torch.rand(B, T, S, 13, generator=g).to(iodt)
+    L = torch.rand(B, T, H, generator=g).to(iodt)
+    p = orc.init_params(S, 13, H, seed=3)
+    model = _model_from(p, S, H, math)
+    params = [q.detach() for q in model.hot_path_parameters()]
+    Ad, Xd, Ld = A.to(dev), X.to(dev), L.to(dev)
+    y_tol = (Y_TOL if math == "f16x3" else F16_Y_TOL) + IO_ROUND[iodt]
+    g_tol = G_TOL if math == "f16x3" else F16_G_TOL
+
+    def run(Xs, Ls, scale=1.0):
+        Y, stash, d = gcn_gru_forward_raw(Ad, Xs, params, model.math, want_stash=True, labels=Ls)
+        grads = [torch.empty_like(q) for q in params]
+        loss = torch.empty((), device=dev)
+        gcn_gru_backward_mse_raw(d, Ad, Xs, params, Y, Ls, stash, grads, loss, scale, part=7 | 8)
+        return Y, grads, float(loss)
+
+    Y, G, loss = run(Xd, Ld)
+    Y1, G1, l1 = run(Xd[: B // 2].contiguous(), Ld[: B // 2].contiguous(), 0.5)
+    Y2, G2, l2 = run(Xd[B // 2:].contiguous(), Ld[B // 2:].contiguous(), 0.5)
+    assert torch.equal(Y[: B // 2], Y1) and torch.equal(Y[B // 2:], Y2)
+    assert abs(0.5 * (l1 + l2) - loss) <= 1e-6 * max(1.0, loss)
+    for a, b, c in zip(G, G1, G2):
+        assert rel_to_max((b + c).cpu(), a.cpu()) <= 1e-5
+    _, G4, _ = run(Xd, Ld, 4.0)
+    for a, b in zip(G, G4):
+        assert torch.equal(a * 4.0, b)
+    n = 256
+    Yo, loss_o, go = _oracle_step(A, X[:n].float(), L[:n].float(), p)
+    Yn, Gn, ln = run(Xd[:n].contiguous(), Ld[:n].contiguous())
+    assert torch.equal(Yn, Y[:n])
+    assert max_abs(Yn.float().cpu(), Yo) <= y_tol
+    assert abs(ln - float(loss_o)) <= (2e-3 if math == "f16" else 1e-5) * max(1.0, float(loss_o))
+    for k, gk in zip(PARAM_KEYS, Gn):
+        assert rel_to_max(gk.cpu(), go[k]) <= g_tol, k

@@ -15,12 +15,13 @@ MATH_F16X3 = 1
 MATH_F16 = 2
 ADJ_DENSE = 0
 ADJ_CSR = 1
+IO_F32, IO_F16, IO_BF16 = 0, 1, 2   # wgnn_io: element type of X, Y and the labels
 STATUS_BYTES = 256          # WGNN_STATUS_BYTES: status block at the start of every workspace
 
 
 class Dims(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("S", C.c_int32), ("F", C.c_int32), ("H", C.c_int32),
-                ("math", C.c_int32), ("adj_format", C.c_int32), ("nnz", C.c_int32)]
+                ("math", C.c_int32), ("adj_format", C.c_int32), ("nnz", C.c_int32), ("io", C.c_int32)]
 
 
 class Params(C.Structure):

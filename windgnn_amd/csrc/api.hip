@@ -123,6 +123,11 @@ int check_dims(const wgnn_dims* d) {
   if (d->F != 13) return WGNN_ERR_SHAPE;            // the reference hard-codes 13 (step6:16)
   if ((int64_t)d->B * d->T > (1 << 30)) return WGNN_ERR_SHAPE;
   if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3 && d->math != WGNN_MATH_F16) return WGNN_ERR_DTYPE;
+  if (d->io != WGNN_IO_F32 && d->io != WGNN_IO_F16 && d->io != WGNN_IO_BF16) return WGNN_ERR_DTYPE;
+  // 16-bit X / Y / labels: only the fp16-plane kernel family with the dense LDS-resident GCN and the register-resident GRU
+  if (d->io != WGNN_IO_F32 &&
+      (d->math == WGNN_MATH_F32 || d->adj_format != WGNN_ADJ_DENSE || d->S > 64 || !grux_shape_supported(d->H)))
+    return WGNN_ERR_UNSUPPORTED;
   if (d->adj_format == WGNN_ADJ_CSR) {
     if (d->nnz < 1 || (int64_t)d->nnz > (int64_t)d->S * d->S) return WGNN_ERR_SHAPE;
   } else if (d->adj_format == WGNN_ADJ_DENSE) {
@@ -171,8 +176,8 @@ size_t wgnn_stash_bytes(const wgnn_dims* d) {
   return sizeof(float) * make_layout(d).stash_floats;
 }
 
-static int fwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* labels,
-                    float* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream) {
+static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* labels,
+                    void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
   if (!A || !X || !p || !Y || !workspace) return WGNN_ERR_NULL;
@@ -197,11 +202,12 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const float* X, const wg
                               (int)L.Ip, status, st);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gcn)    // CSR adjacency: fp32 SpMM layers, layer 2 writes the g planes
-      rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight,
-                               p->conv2_bias, sf ? sf + L.st_h1 : ws + L.ws_h1, nullptr, g, L.Ip, full, status, st);
+      rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, (const float*)X, p->conv1_weight, p->conv1_bias,
+                               p->conv2_weight, p->conv2_bias, sf ? sf + L.st_h1 : ws + L.ws_h1, nullptr, g, L.Ip, full,
+                               status, st);
     else
-      rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                            (int)L.Ip, full, status, st);
+      rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight,
+                            p->conv2_bias, g, (int)L.Ip, full, status, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
@@ -211,20 +217,20 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const float* X, const wg
       rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 0, p->b_hh, (int)L.H, ws + L.ws_hhp_f, L.np_g3, (int)L.Hp,
                                 status, st);
       if (rc != WGNN_OK) return rc;
-      return launch_gru_gen_fwd_x3(d->B, d->T, d->H, GI, (int)L.Gp, ws + L.ws_hhp_f, L.np_g3, p->b_hh, Y, gates,
+      return launch_gru_gen_fwd_x3(d->B, d->T, d->H, GI, (int)L.Gp, ws + L.ws_hhp_f, L.np_g3, p->b_hh, (float*)Y, gates,
                                    sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, ws + L.ws_kp_f, ws + L.ws_hc, full,
                                    st);
     }
     // labels (wgnn_fwd_loss): the recurrence also leaves the MSE partial sums / maxima of (Y - labels) in the stash
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
-                           full, status, sf ? labels : nullptr, sf ? sf + L.st_stats : nullptr, st);
+                           full, status, sf ? labels : nullptr, sf ? sf + L.st_stats : nullptr, d->io, st);
   }
   if (L.gen_gcn) {
     float* h1 = sf ? sf + L.st_h1 : ws + L.ws_h1;    // layer-1 activations: kept for the backward if there is a stash
-    rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight,
-                             p->conv2_bias, h1, g, nullptr, L.Ip, false, nullptr, st);
+    rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, (const float*)X, p->conv1_weight, p->conv1_bias,
+                             p->conv2_weight, p->conv2_bias, h1, g, nullptr, L.Ip, false, nullptr, st);
   } else {
-    rc = launch_gcn2_fwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
+    rc = launch_gcn2_fwd((int)L.BT, d->S, A, (const float*)X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
                          (int)L.Ip, st);
   }
   if (rc != WGNN_OK) return rc;
@@ -236,22 +242,22 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const float* X, const wg
   rc = launch_gemm_f32(ga, st);
   if (rc != WGNN_OK) return rc;
   if (L.gen_gru)
-    return launch_gru_gen_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, ws + L.ws_gh, st);
-  return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, st);
+    return launch_gru_gen_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, ws + L.ws_gh, st);
+  return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, st);
 }
 
-int wgnn_fwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, float* Y, void* stash,
+int wgnn_fwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, void* Y, void* stash,
              void* workspace, size_t workspace_bytes, void* stream) {
   return fwd_impl(d, A, X, p, nullptr, Y, stash, workspace, workspace_bytes, stream);
 }
 
-int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* labels,
-                  float* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream) {
+int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* labels,
+                  void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream) {
   if (!labels || !stash) return WGNN_ERR_NULL;
   return fwd_impl(d, A, X, p, labels, Y, stash, workspace, workspace_bytes, stream);
 }
 
-int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
+int wgnn_bwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* Y,
              const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
              void* stream) {
   return wgnn_bwd_part(d, A, X, p, Y, dY, stash, g, workspace, workspace_bytes, stream, 7);
@@ -262,11 +268,14 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
 namespace {
 // The backward behind wgnn_bwd_part (dY given) and wgnn_bwd_mse_part (labels given: dY = 2 (Y - labels) grad_scale / n
 // is never written when the register-resident f16x3 recurrence runs; loss[0] = mean((Y - labels)^2)).
-int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
-             const float* dY, const float* labels, float grad_scale, float* loss, const void* stash,
+int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_params* p, const void* Yv,
+             const float* dY, const void* labelsv, float grad_scale, float* loss, const void* stash,
              const wgnn_grads* g, void* workspace, size_t workspace_bytes, void* stream, int which) {
   if (which < 1 || which > 15 || (which & 7) == 0) return WGNN_ERR_SHAPE;
   const bool do_rec = which & 1, do_gcn = which & 2, do_wg = which & 4;
+  const float* X = (const float*)Xv;                 // io-typed (d->io): only the kernels that take `io` see 16-bit data
+  const float* Y = (const float*)Yv;
+  const float* labels = (const float*)labelsv;
   const bool stats_ready = (which & 8) && labels;   // wgnn_fwd_loss left the MSE partials in the stash
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
@@ -291,6 +300,8 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
   const bool x3 = L.x3;
   const bool full = d->math == WGNN_MATH_F16X3;
   const bool fused_loss = labels && x3 && !L.gen_gru;      // the recurrence kernel forms dY from the labels itself
+  // 16-bit labels / Y: the statistics must come from wgnn_fwd_loss (the stand-alone pass reads fp32 only)
+  if (d->io != WGNN_IO_F32 && labels && do_rec && !(fused_loss && stats_ready)) return WGNN_ERR_UNSUPPORTED;
   if (labels && !fused_loss && do_rec) {                   // other kernels: materialise dY in the workspace
     rc = launch_mse(Y, labels, (int64_t)L.BT * L.H, grad_scale, ws + L.ws_dY, loss, scales + 64, st);
     if (rc != WGNN_OK) return rc;
@@ -321,8 +332,8 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
         rc = launch_gru_gen_bwd_x3(d->B, d->T, d->H, ws + L.ws_hhp_b, L.np_h, Y, dY, gates, scales, dGIh, dGHh,
                                    (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, ws + L.ws_kp_b, ws + L.ws_dc, full, st);
       } else {
-        rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Y, fused_loss ? nullptr : dY, fused_loss ? labels : nullptr,
-                             gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
+        rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Yv, fused_loss ? nullptr : dY, fused_loss ? labelsv : nullptr,
+                             d->io, yph, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
       }
       if (rc != WGNN_OK) return rc;
     }
@@ -364,7 +375,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
       return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
                                  L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
                                  g->conv2_weight, g->conv2_bias, st);
-    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
+    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, Xv, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                           scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, st);
     if (rc != WGNN_OK) return rc;
     return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT, d->S), g->conv1_weight, g->conv1_bias,
@@ -422,15 +433,15 @@ int bwd_impl(const wgnn_dims* d, const float* A, const float* X, const wgnn_para
 
 extern "C" {
 
-int wgnn_bwd_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
+int wgnn_bwd_part(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* Y,
                   const float* dY, const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
                   void* stream, int which) {
   if (!dY) return WGNN_ERR_NULL;
   return bwd_impl(d, A, X, p, Y, dY, nullptr, 1.f, nullptr, stash, g, workspace, workspace_bytes, stream, which);
 }
 
-int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const float* X, const wgnn_params* p, const float* Y,
-                      const float* labels, float grad_scale, float* loss, const void* stash, const wgnn_grads* g,
+int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* Y,
+                      const void* labels, float grad_scale, float* loss, const void* stash, const wgnn_grads* g,
                       void* workspace, size_t workspace_bytes, void* stream, int which) {
   if (!labels) return WGNN_ERR_NULL;
   return bwd_impl(d, A, X, p, Y, nullptr, labels, grad_scale, loss, stash, g, workspace, workspace_bytes, stream,

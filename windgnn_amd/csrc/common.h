@@ -106,9 +106,9 @@ int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
 size_t grux_gates_floats(int B, int T, int H);   // gate stash of the register-resident recurrences (their own layout)
-int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                    float* gates, void* y_planes, bool x3, unsigned* status, const float* labels, float* stat_part,
-                    hipStream_t st);
+int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, void* Y,
+                    float* gates, void* y_planes, bool x3, unsigned* status, const void* labels, float* stat_part,
+                    int io /*wgnn_io of Y and labels*/, hipStream_t st);
 int grux_blocks(int B);   // workgroups of launch_grux_fwd = MSE partial pairs it writes when given labels
 // loss and scales {2^k, 2^-k, 2 grad_scale / n} from nblk partial pairs (sum | max) already computed
 int launch_mse_stats_finalize(const float* part, int nblk, int64_t n, float grad_scale, float* loss, float* scales,
@@ -118,8 +118,8 @@ int mse_stats_blocks();
 // dGI planes [B*T][ldd] (3H layout) and the n third of dGH alone, dGHn planes [B*T][grux_hn(H)] (dGH's r and z thirds equal dGI's)
 int grux_hn(int H);       // row width (halfs) of the dGHn planes: 8*ceil(H/8)
 int grux_msplit(int H);   // 8*ceil(2H/8): first GEMM row of the dGHn block in the dW_hh product
-int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
-                    const float* gates,
+int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
+                    const void* y_planes /*the stash's h planes: h_{t-1} when io != 0*/, const float* gates,
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st);
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,
@@ -135,9 +135,9 @@ int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float*
 size_t gcnx2_bwd_partial_floats(int ntiles);
 int gcnx_bwd_grid(int ntiles, int S);
 // g_planes: fp16 hi plane [ntiles][ldg] followed by the lo plane; column S*13 holds 1.0, later columns 0
-int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io /*wgnn_io of X*/, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, hipStream_t st);
-int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
                      int scale_in, float* partial, bool x3, hipStream_t st);
 // plane GEMMs (pgemm.hip)

@@ -157,6 +157,37 @@ __device__ __forceinline__ void gload_pairs(f32x2 (&r)[NP], const float* __restr
     }
   }
 }
+// The same for an io-typed tensor (wgnn_io): 16-bit pairs are one dword, kept raw in r[k][0] until io_pair() converts
+// them at staging time (so the wait for the prefetch stays where it was).  `tile_elems` = element offset of the tile.
+template <int NP>
+__device__ __forceinline__ void gload_pairs_io(f32x2 (&r)[NP], const void* __restrict__ base, size_t tile_elems,
+                                               int lane, int I, int io) {
+  if (io == 0) {
+    gload_pairs<NP>(r, (const float*)base + tile_elems, lane, I);
+    return;
+  }
+  const unsigned short* src = (const unsigned short*)base + tile_elems;
+  const int npairs = (I + 1) / 2;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (64 * k < npairs) {
+      const int p = lane + 64 * k;
+      r[k][0] = __builtin_bit_cast(float, *(const unsigned*)(src + 2 * (p < npairs ? p : npairs - 1)));
+    }
+  }
+}
+__device__ __forceinline__ f32x2 io_pair(f32x2 raw, int io) {
+  if (io == 0) return raw;
+  const unsigned u = __builtin_bit_cast(unsigned, raw[0]);
+  f32x2 v;
+  if (io == 1) {
+    v = __builtin_convertvector(__builtin_bit_cast(h2, u), f32x2);
+  } else {   // bf16: the upper half of an fp32
+    v[0] = __builtin_bit_cast(float, u << 16);
+    v[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+  }
+  return v;
+}
 template <int NP>
 __device__ __forceinline__ void gload_pairs_h(h2 (&r)[NP], const _Float16* __restrict__ src, int lane, int I) {
   const int npairs = (I + 1) / 2;
@@ -184,7 +215,7 @@ constexpr int FWD_WAVES = 8;   // waves per forward block (A fragments are share
 
 template <int NT, bool X3>
 __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
-                                                       const float* __restrict__ X, const float* __restrict__ W1,
+                                                       const void* __restrict__ X, int io, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const float* __restrict__ b2, _Float16* __restrict__ ghi,
                                                        _Float16* __restrict__ glo, int ldp, unsigned* status) {
@@ -256,20 +287,21 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       if (64 * k < npairs) {       // wave-uniform
-        xb[map.o0[k]] = xr[k][0];
-        xb[map.o1[k]] = xr[k][1];
+        const f32x2 v = io_pair(xr[k], io);
+        xb[map.o0[k]] = v[0];
+        xb[map.o1[k]] = v[1];
       }
     }
   };
   if (wave_id < ntiles) {
-    gload_pairs<NP>(xr, X + (size_t)wave_id * I, lane, I);
+    gload_pairs_io<NP>(xr, X, (size_t)wave_id * I, lane, I, io);
     stage_x();
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     asm volatile("" ::: "memory");                    // keep the A-fragment reads in LDS (no hoisting into VGPRs)
     wave_lds_fence();                                 // this tile's X is staged
     const bool more = tile + nwaves < ntiles;
-    if (more) gload_pairs<NP>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch the next tile
+    if (more) gload_pairs_io<NP>(xr, X, (size_t)(tile + nwaves) * I, lane, I, io);   // prefetch the next tile
 
     f32x4 U[NT];
 #pragma unroll
@@ -351,7 +383,7 @@ constexpr int bwd_waves(int NT) { return 12; }   // (16 waves at 128 VGPRs spill
 
 template <int NT, bool X3>
 __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
-                                                       const float* __restrict__ X, const float* __restrict__ W1,
+                                                       const void* __restrict__ X, int io, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const _Float16* __restrict__ gact, int ld_g,
                                                        const float* __restrict__ dg, const float* __restrict__ scales,
@@ -432,7 +464,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
   f32x2 xr[NP], dr[NP];
   h2 gr[NP];
   if (wave_id < ntiles) {
-    gload_pairs<NP>(xr, X + (size_t)wave_id * I, lane, I);
+    gload_pairs_io<NP>(xr, X, (size_t)wave_id * I, lane, I, io);
     gload_pairs_h<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
     gload_pairs<NP>(dr, dg + (size_t)wave_id * I, lane, I);
   }
@@ -442,8 +474,9 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       if (64 * k < npairs) {       // wave-uniform; lanes past the tile write the dump slot
-        xb[map.o0[k]] = xr[k][0];
-        xb[map.o1[k]] = xr[k][1];
+        const f32x2 xv = io_pair(xr[k], io);
+        xb[map.o0[k]] = xv[0];
+        xb[map.o1[k]] = xv[1];
         db[map.o0[k]] = (float)gr[k][0] > 0.f ? dr[k][0] * s_in : 0.f;     // dZ2 = dg * (g > 0), range-scaled
         db[map.o1[k]] = (float)gr[k][1] > 0.f ? dr[k][1] * s_in : 0.f;
       }
@@ -451,7 +484,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
     wave_lds_fence();
     if (tile + nwaves < ntiles) {                               // prefetch the next tile under this one's math
       const size_t nt = (size_t)(tile + nwaves);
-      gload_pairs<NP>(xr, X + nt * I, lane, I);
+      gload_pairs_io<NP>(xr, X, nt * I, lane, I, io);
       gload_pairs_h<NP>(gr, gact + nt * ld_g, lane, I);
       gload_pairs<NP>(dr, dg + nt * I, lane, I);
     }
@@ -585,24 +618,24 @@ int grid_x(int ntiles, int S) {
 size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)256 * PART; }
 int gcnx_bwd_grid(int ntiles, int S) { return grid_x(ntiles, S); }
 
-int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status,
                      hipStream_t st) {
   _Float16* ghi = (_Float16*)g_planes;
   _Float16* glo = ghi + (size_t)ntiles * ldg;
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
-  const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
+  const double by = (double)ntiles * S * 13 * (io ? 2.0 : 4.0) + (double)ntiles * S * 13 * 4.0;   // X in, g planes out
   int gx = cdiv_i(ntiles, FWD_WAVES);
   gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
   const dim3 grid(gx);
 #define FWD_CASE(NT)                                                                                              \
   if (x3)                                                                                                         \
     PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                           \
-                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, true>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, b2, \
+                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, true>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, io, W1, b1, W2, b2, \
                                    ghi, glo, ldg, status));                                                       \
   else                                                                                                            \
     PROF_LAUNCH("gcnx_fwd_kernel<" #NT ",f16>", fl, by * 0.75, st,                                                \
-                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, false>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, \
+                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, false>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, io, W1, b1, W2, \
                                    b2, ghi, glo, ldg, status))
   switch ((S + 15) / 16) {
     case 1: FWD_CASE(1); break;
@@ -616,22 +649,22 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const float* X, const fl
   return WGNN_OK;
 }
 
-int launch_gcnx2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
                      int scale_in, float* partial, bool x3, hipStream_t st) {
   const _Float16* g = (const _Float16*)g_planes;   // hi plane carries the sign: g > 0 <=> hi > 0
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   // what the launch reads: X and dg as fp32, and the fp16 hi plane of g (2 bytes x ldg per tile) as the ReLU mask
-  const double by = (double)ntiles * (S * 13 * 4.0 * 2.0 + ldg * 2.0);
+  const double by = (double)ntiles * (S * 13 * (io ? 2.0 : 4.0) + S * 13 * 4.0 + ldg * 2.0);
   const dim3 grid(grid_x(ntiles, S));
 #define BWD_CASE(NT)                                                                                               \
   if (x3)                                                                                                          \
     PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                            \
-                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, W1, b1, W2, g,  \
+                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, io, W1, b1, W2, g,  \
                                    ldg, dg, scales, scale_in, partial));                                           \
   else                                                                                                             \
     PROF_LAUNCH("gcnx_bwd_kernel<" #NT ",f16>", fl, by, st,                                                        \
-                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, W1, b1, W2, g, \
+                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, io, W1, b1, W2, g, \
                                    ldg, dg, scales, scale_in, partial))
   switch ((S + 15) / 16) {
     case 1: BWD_CASE(1); break;

@@ -64,6 +64,18 @@ __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {   // weights: 
   f.lo = __builtin_bit_cast(h8, lo);
   return f;
 }
+// io-typed element access (wgnn_io): 0 = fp32, 1 = fp16, 2 = bf16 (round to nearest even on store)
+__device__ __forceinline__ float io_load(const void* p, int idx, int io) {
+  if (io == 0) return ((const float*)p)[idx];
+  const unsigned short u = ((const unsigned short*)p)[idx];
+  if (io == 1) return (float)__builtin_bit_cast(_Float16, u);
+  return __builtin_bit_cast(float, (unsigned)u << 16);
+}
+__device__ __forceinline__ void io_store(void* p, int idx, float v, int io) {
+  if (io == 0) { ((float*)p)[idx] = v; return; }
+  if (io == 1) { ((_Float16*)p)[idx] = (_Float16)v; return; }
+  ((__bf16*)p)[idx] = (__bf16)v;      // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+}
 template <bool X3>
 __device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, float v) {
   const _Float16 h = (_Float16)v;
@@ -75,11 +87,11 @@ __device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, f
 template <int KS, bool X3>   // K steps of 32 over the hidden index (+ the ones column): KS = ceil((H+1)/32)
 __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const float* __restrict__ GI, int ldgi,
                                                             const float* __restrict__ Whh,
-                                                            const float* __restrict__ bhh, float* __restrict__ Y,
+                                                            const float* __restrict__ bhh, void* __restrict__ Y,
                                                             float* __restrict__ gates, _Float16* __restrict__ yp_hi,
                                                             _Float16* __restrict__ yp_lo, unsigned* status,
-                                                            const float* __restrict__ Lab,
-                                                            float* __restrict__ stat_part) {
+                                                            const void* __restrict__ Lab,
+                                                            float* __restrict__ stat_part, int io) {
   constexpr int HP = 32 * KS;                      // plane row width (halfs): h, then 1.0 at column H, then 0
   constexpr int HS = 32 * KS + 8;                  // row stride in halfs: 16-B aligned, conflict-free reads
   // h state is double-buffered: step t reads buffer t&1 and writes h_t into the other one, so a single
@@ -122,7 +134,8 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   // Addressing: one workgroup-uniform 64-bit base per array (the workgroup's first window) plus 32-bit lane
   // offsets.  Row indices are clamped so every load is unconditional.
   const float* GIw = GI + (size_t)b0 * T * ldgi;
-  float* Yw = Y + (size_t)b0 * T * H;
+  const int esz = io ? 2 : 4;                      // bytes per element of Y and the labels (wgnn_io)
+  void* Yw = (char*)Y + (size_t)b0 * T * H * esz;
   // gate stash in this kernel's own register layout, [workgroup][t][wave][r | z | n | gh_n][lane] x float4 (the 4 window
   // rows a lane owns): one 16-byte store per lane and component (a full 1 KB per wave-instruction) instead of sixteen
   // 4-byte stores in 64-byte segments; the BPTT kernel (same thread <-> (rows, unit) map) reads it back the same way.
@@ -141,7 +154,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   }
   // wgnn_fwd_loss: the MSE statistics (sum of squares, max |Y - L|) are taken here, from the h this kernel
   // holds in registers, so no later pass re-reads Y and the labels for them
-  const float* Labw = Lab ? Lab + (size_t)b0 * T * H : nullptr;
+  const void* Labw = Lab ? (const char*)Lab + (size_t)b0 * T * H * esz : nullptr;
   float lab[4] = {0.f, 0.f, 0.f, 0.f}, labn[4] = {0.f, 0.f, 0.f, 0.f};
   float ssum = 0.f, smax = 0.f;
   float gi[3][4], gin[3][4];
@@ -153,7 +166,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       dst[0][r] = GIw[o];
       dst[1][r] = GIw[o + H];
       dst[2][r] = GIw[o + 2 * H];
-      if (Lab) ldst[r] = Labw[(rowt[r] + tc) * H + jc];
+      if (Lab) ldst[r] = io_load(Labw, (rowt[r] + tc) * H + jc, io);
     }
   };
   load_gi(0, gi, lab);
@@ -195,7 +208,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         hnew[r] = (1.f - zg) * ng + zg * hold[r];
         if (rowok[r]) {
           const int bt = rowt[r] + t;
-          Yw[bt * H + j] = hnew[r];
+          io_store(Yw, bt * H + j, hnew[r], io);      // 16-bit I/O: rounded once, here; the statistics use hnew itself
           if (Lab) {
             const float dl = hnew[r] - lab[r];
             ssum = fmaf(dl, dl, ssum);
@@ -271,8 +284,10 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
 // for the copy-out; the W_hh^T fragments' k index follows the same layout.
 template <int KSB, bool X3>   // K steps of 32 over the padded dgh row: KSB = ceil((MS + H) / 32)
 __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
-                                                            const float* __restrict__ Y, const float* __restrict__ dY,
-                                                            const float* __restrict__ Lab,
+                                                            const void* __restrict__ Y, const float* __restrict__ dY,
+                                                            const void* __restrict__ Lab, int io,
+                                                            const _Float16* __restrict__ yp_hi,
+                                                            const _Float16* __restrict__ yp_lo, int hp_ld,
                                                             const float* __restrict__ gates,
                                                             const float* __restrict__ scales,
                                                             _Float16* __restrict__ dGI_hi, _Float16* __restrict__ dGI_lo,
@@ -311,8 +326,20 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   }
   const int NW = (H + 15) / 16;                              // gate stash: grux_fwd_kernel's register layout
   const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * GREC * 64 + lane;
-  const float* dYw = (Lab ? Lab : dY) + (size_t)b0 * T * H;
-  const float* Yw = Y + (size_t)b0 * T * H;
+  // 16-bit I/O: Y on the wire is rounded, so h_{t-1} (and the Y of the fused dY) comes from the stash's h planes,
+  // hi + lo = the forward's fp32 h to 2^-22; explicit dY is always fp32, labels are io-typed
+  const int esz = io ? 2 : 4;
+  const void* Labw = Lab ? (const char*)Lab + (size_t)b0 * T * H * esz : nullptr;
+  const float* dYw = dY ? dY + (size_t)b0 * T * H : nullptr;
+  const float* Yw = (const float*)Y + (size_t)b0 * T * H;
+  const _Float16* yph = yp_hi + (size_t)b0 * T * hp_ld;
+  const _Float16* ypl = yp_lo + (size_t)b0 * T * hp_ld;
+  auto load_h = [&](int bt) {     // h of row (b, t) = local row index bt
+    if (io == 0) return Yw[bt * H + jc];
+    float v = (float)yph[bt * hp_ld + jc];
+    if (X3) v += (float)ypl[bt * hp_ld + jc];
+    return v;
+  };
   int rowt[4];
   bool rowok[4];
 #pragma unroll
@@ -362,12 +389,12 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int bt = rowt[r] + tc;
-      s.dy[r] = dYw[bt * H + jc];
+      s.dy[r] = Lab ? io_load(Labw, bt * H + jc, io) : dYw[bt * H + jc];
       s.r[r] = r4[r];
       s.z[r] = z4[r];
       s.n[r] = n4[r];
       s.ghn[r] = g4[r];
-      const float hp = Yw[(bt - (tc > 0 ? 1 : 0)) * H + jc];
+      const float hp = load_h(bt - (tc > 0 ? 1 : 0));
       s.hp[r] = tc > 0 ? hp : 0.f;
     }
   };
@@ -376,7 +403,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   float ycur[4] = {0.f, 0.f, 0.f, 0.f};
   if (Lab) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ycur[r] = Yw[(rowt[r] + T - 1) * H + jc];
+    for (int r = 0; r < 4; ++r) ycur[r] = load_h(rowt[r] + T - 1);
   }
   f32x4 dhn = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
@@ -452,25 +479,26 @@ int grux_hp(int H) { return 32 * cdiv_i(H + 1, 32); }
 size_t grux_gates_floats(int B, int T, int H) { return (size_t)cdiv_i(B, MB) * T * cdiv_i(H, 16) * GREC * 64 * 4; }
 int grux_blocks(int B) { return cdiv_i(B, MB); }
 
-int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, void* Y,
                     float* gates, void* y_planes /*nullable: 2 x [B*T+1][grux_hp(H)] halfs*/, bool x3, unsigned* status,
-                    const float* labels /*nullable*/, float* stat_part /*2 * grux_blocks(B) floats if labels*/,
+                    const void* labels /*nullable*/, float* stat_part /*2 * grux_blocks(B) floats if labels*/, int io,
                     hipStream_t st) {
   _Float16* yh = (_Float16*)y_planes;
   _Float16* yl = yh ? yh + ((size_t)B * T + 1) * grux_hp(H) : nullptr;   // each plane has B*T + 1 rows
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H,
-               by = bt * 4.0 * (3 * H + H + (labels ? H : 0)) + (gates ? 4.0 * grux_gates_floats(B, T, H) : 0.0);
+               by = bt * (4.0 * 3 * H + (io ? 2.0 : 4.0) * (H + (labels ? H : 0))) +
+                    (gates ? 4.0 * grux_gates_floats(B, T, H) : 0.0);
   const dim3 grid(cdiv_i(B, MB));
 #define FCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
     PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                             \
                 hipLaunchKernelGGL((grux_fwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, \
-                                   Y, gates, yh, yl, status, labels, stat_part));                                  \
+                                   Y, gates, yh, yl, status, labels, stat_part, io));                              \
   else                                                                                                             \
     PROF_LAUNCH("grux_fwd_kernel<" #K ",f16>", fl, by, st,                                                         \
                 hipLaunchKernelGGL((grux_fwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh,    \
-                                   bhh, Y, gates, yh, yl, status, labels, stat_part))
+                                   bhh, Y, gates, yh, yl, status, labels, stat_part, io))
   switch (cdiv_i(H + 1, 32)) {
     case 1: FCASE(1); break;
     case 2: FCASE(2); break;
@@ -486,9 +514,12 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
 int grux_hn(int H) { return 8 * cdiv_i(H, 8); }
 int grux_msplit(int H) { return 8 * cdiv_i(2 * H, 8); }
 
-int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
-                    const float* gates,
+int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
+                    const void* y_planes, const float* gates,
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st) {
+  const _Float16* yh = (const _Float16*)y_planes;
+  const _Float16* yl = yh + ((size_t)B * T + 1) * grux_hp(H);
+  const int hp_ld = grux_hp(H);
   _Float16* ih = (_Float16*)dGI_planes;
   _Float16* il = ih + (size_t)B * T * ldd;
   _Float16* nh = (_Float16*)dGHn_planes;
@@ -496,17 +527,18 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const float* Y, const
   const int ksb = cdiv_i(grux_msplit(H) + H, 32);
   if (ldd % 8 != 0 || ldd < 3 * H || ldd > 32 * ksb) return WGNN_ERR_SHAPE;
   const double bt = (double)B * T;
-  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (2 * H + 3 * H + H) + 4.0 * grux_gates_floats(B, T, H);
+  const double fl = bt * 2.0 * 3 * H * H,
+               by = bt * ((io ? 2.0 + 4.0 : 4.0 + 4.0) * H + 4.0 * (3 * H + H)) + 4.0 * grux_gates_floats(B, T, H);
   const dim3 grid(cdiv_i(B, MB));
 #define BCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
     PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                             \
                 hipLaunchKernelGGL((grux_bwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
-                                   gates, scales, ih, il, ldd, nh, nl));                                                  \
+                                   io, yh, yl, hp_ld, gates, scales, ih, il, ldd, nh, nl));                               \
   else                                                                                                             \
     PROF_LAUNCH("grux_bwd_kernel<" #K ",f16>", fl, by * 0.75, st,                                                  \
                 hipLaunchKernelGGL((grux_bwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
-                                   gates, scales, ih, il, ldd, nh, nl))
+                                   io, yh, yl, hp_ld, gates, scales, ih, il, ldd, nh, nl))
   switch (ksb) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;

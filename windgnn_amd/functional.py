@@ -13,13 +13,17 @@ PARAM_ORDER = ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias",
                "gru.weight_ih_l0", "gru.weight_hh_l0", "gru.bias_ih_l0", "gru.bias_hh_l0")
 
 
-def _require_gpu(*tensors: torch.Tensor) -> None:
+_IO_OF = {torch.float32: _lib.IO_F32, torch.float16: _lib.IO_F16, torch.bfloat16: _lib.IO_BF16}
+
+
+def _require_gpu(*tensors: torch.Tensor, io_ok: bool = False) -> None:
+    """io_ok: the tensor is one of the "on the wire" tensors (X, Y, labels), which may also be fp16 / bf16 (wgnn_io)."""
     for t in tensors:
         if not t.is_cuda:
             raise RuntimeError(
                 "windgnn_amd runs on an MI355X (HIP) only: got a %s tensor. There is no CPU fallback; "
                 "use the oracle under oracle/ for CPU checks." % t.device)
-        if t.dtype != torch.float32:
+        if t.dtype != torch.float32 and not (io_ok and t.dtype in _IO_OF):
             raise RuntimeError("windgnn_amd: expected float32 tensors, got %s" % t.dtype)
 
 
@@ -113,20 +117,24 @@ def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32
     """Y[B,T,H], stash = wgnn_fwd(...).  X is [B,T,S,F].  labels [B,T,H]: wgnn_fwd_loss (the MSE statistics of
     (Y - labels) are left in the stash for gcn_gru_backward_mse_raw(..., part | 8))."""
     lib = _lib.load()
-    _require_gpu(X, *params)
+    _require_gpu(X, io_ok=True)
+    _require_gpu(*params)
     B, T, S, F = X.shape
     A, fmt, nnz = _adj(A, S)
     H = params[5].shape[1]
-    d = _lib.Dims(B, T, S, F, H, math, fmt, nnz)
+    d = _lib.Dims(B, T, S, F, H, math, fmt, nnz, _IO_OF[X.dtype])     # X's dtype is the I/O type: Y comes back in it
     ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
     if ws_bytes == 0:
-        _lib.check(-5 if F == 13 else -2, "wgnn_workspace_bytes(B=%d,T=%d,S=%d,F=%d,H=%d)" % (B, T, S, F, H))
+        _lib.check(-5 if F == 13 else -2, "wgnn_workspace_bytes(B=%d,T=%d,S=%d,F=%d,H=%d,math=%d,io=%s)"
+                   % (B, T, S, F, H, math, X.dtype))
     ws = _Workspace.get(X.device, ws_bytes)
     stash = torch.empty(lib.wgnn_stash_bytes(C.byref(d)), dtype=torch.uint8, device=X.device) if want_stash else None
-    Y = torch.empty(B, T, H, dtype=torch.float32, device=X.device)
+    Y = torch.empty(B, T, H, dtype=X.dtype, device=X.device)
     ps = _params_struct(_lib.Params, params)
     if labels is not None:
-        _require_gpu(labels)
+        _require_gpu(labels, io_ok=True)
+        if labels.dtype != X.dtype:
+            raise RuntimeError("windgnn_amd: labels are %s but X is %s (one I/O type per call)" % (labels.dtype, X.dtype))
         if labels.numel() != Y.numel() or not want_stash:
             raise RuntimeError("windgnn_amd: wgnn_fwd_loss needs a stash and labels of Y's size, got %s vs %s"
                                % (tuple(labels.shape), tuple(Y.shape)))
@@ -157,7 +165,9 @@ def gcn_gru_backward_mse_raw(d, A, X, params, Y, L, stash, grads: Sequence[torch
     """wgnn_bwd_mse_part: the backward of grad_scale * mean((Y - L)^2) with the loss call folded in (src/main.py:72,79);
     `loss` (0-dim device tensor) receives mean((Y - L)^2) from the call that has part bit 1."""
     lib = _lib.load()
-    _require_gpu(L)
+    _require_gpu(L, io_ok=True)
+    if L.dtype != Y.dtype:
+        raise RuntimeError("windgnn_amd: labels are %s but Y is %s (one I/O type per call)" % (L.dtype, Y.dtype))
     if L.numel() != Y.numel():
         raise RuntimeError("windgnn_amd: MSE operands differ in size: %s vs %s" % (tuple(Y.shape), tuple(L.shape)))
     A = getattr(A, "blob", A)
@@ -199,7 +209,7 @@ class GCNGRUFunction(torch.autograd.Function):
         sizes = [p.numel() for p in params]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=X.device)
         grads = [g.view_as(p) for g, p in zip(flat.split(sizes), params)]
-        gcn_gru_backward_raw(ctx.d, A, X, params, Y, dY.contiguous(), ctx.stash, grads)
+        gcn_gru_backward_raw(ctx.d, A, X, params, Y, dY.float().contiguous(), ctx.stash, grads)   # dY is always fp32
         return (None, None, None, *grads)
 
 

@@ -47,8 +47,9 @@ class _GRUParams(nn.Module):
 
 class GCN_GRU(nn.Module):
     """forward(adj_matrix [S,S], attr_matrix [1,T,S,13]) -> [T, gru_hidden_dim], exactly the
-    reference's contract.  Extension: attr_matrix [B,T,S,13] with B > 1 returns [B,T,H] (B
-    independent windows, h0 = 0 each)."""
+    reference's contract.  Extensions: attr_matrix [B,T,S,13] with B > 1 returns [B,T,H] (B independent windows,
+    h0 = 0 each); a float16 / bfloat16 attr_matrix (math "f16x3" or "f16" only) is read as such and the output comes
+    back in the same type (16-bit I/O, BASELINE's 16-bit configuration) -- parameters and gradients stay fp32."""
 
     def __init__(self, input_dim, hidden_dim, output_dim, gru_input, gru_hidden_dim, math="f32", validate=True):
         super().__init__()
