@@ -70,7 +70,7 @@ Layout make_layout(const wgnn_dims* d) {
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
   {  // r, z, n, gh_n of every step: [B*T][4H] fp32, or the register-resident recurrences' own record layout
-    const size_t plain = L.BT * 4 * L.H, rec = (x3 && !L.gen_gru) ? grux_gates_floats(d->B, d->T, d->H) : 0;
+    const size_t plain = L.BT * 4 * L.H, rec = (x3 && !L.gen_gru) ? grux_gates_floats(d->B, d->T, d->H, d->io) : 0;
     L.st_gates = o; o += al(plain > rec ? plain : rec);
   }
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
@@ -333,7 +333,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
                                    (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, ws + L.ws_kp_b, ws + L.ws_dc, full, st);
       } else {
         rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Yv, fused_loss ? nullptr : dY, fused_loss ? labelsv : nullptr,
-                             d->io, yph, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
+                             d->io, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
       }
       if (rc != WGNN_OK) return rc;
     }

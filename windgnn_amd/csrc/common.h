@@ -105,7 +105,7 @@ int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=
 // split-fp16 GRU recurrences with register-resident weights (grux.hip)
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
-size_t grux_gates_floats(int B, int T, int H);   // gate stash of the register-resident recurrences (their own layout)
+size_t grux_gates_floats(int B, int T, int H, int io);   // gate stash of the register-resident recurrences (their own layout)
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, void* Y,
                     float* gates, void* y_planes, bool x3, unsigned* status, const void* labels, float* stat_part,
                     int io /*wgnn_io of Y and labels*/, hipStream_t st);
@@ -119,7 +119,7 @@ int mse_stats_blocks();
 int grux_hn(int H);       // row width (halfs) of the dGHn planes: 8*ceil(H/8)
 int grux_msplit(int H);   // 8*ceil(2H/8): first GEMM row of the dGHn block in the dW_hh product
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
-                    const void* y_planes /*the stash's h planes: h_{t-1} when io != 0*/, const float* gates,
+                    const float* gates,
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st);
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,

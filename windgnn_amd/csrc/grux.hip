@@ -14,12 +14,16 @@
 #include "common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int MB = 16;
 constexpr int NTHREADS = 512;
-constexpr int GREC = 4;   // 16-byte components of a gate-stash record: r | z | n | gh_n
+// 16-byte components of a gate-stash record: r | z | n | gh_n, plus h_t itself when Y on the wire is 16-bit (the BPTT
+// kernel then takes h_{t-1} from the stash: the rounded Y is not the forward's hidden state)
+__host__ __device__ constexpr int grec(int io) { return io ? 5 : 4; }
 
 struct Frag { h8 hi, lo; };
 
@@ -143,6 +147,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   // WRONG for trained weights -- saturated gates need r (1 - r) to fp32's own precision (8 % gradient error on the
   // wind_gnn_7.pth fixture).
   const int NW = (H + 15) / 16;
+  const int GREC = grec(io);
   f32x4* gatesw = gates ? (f32x4*)gates + ((size_t)blockIdx.x * T * NW + wave) * GREC * 64 + lane : nullptr;
   int rowt[4];            // (local window row) * T, clamped to the last valid window
   bool rowok[4];
@@ -152,13 +157,65 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     rowok[r] = jv && b0 + m < B;
     rowt[r] = (b0 + m < B ? m : B - 1 - b0) * T;
   }
+  // ---- Y out and labels in go through LDS as whole rows: a row (b, t) of Y or of the labels is H contiguous elements,
+  // moved as "units" of 2 elements (8 bytes fp32, 4 bytes fp16 / bf16) by consecutive threads, instead of each owner
+  // lane storing / loading single elements in 64-byte (32-byte at 16 bits) segments.  ytile / ltile are double-buffered
+  // by step parity like hbuf.  Unit q = threadIdx.x + 512 i of the workgroup's 16 rows: fixed for the whole launch.
+  constexpr int HY = HP + 2;                       // fp32 row stride of the tiles (even: 8-byte aligned pairs)
+  __shared__ __attribute__((aligned(16))) float ytile[2 * MB * HY];
+  __shared__ __attribute__((aligned(16))) float ltile[2 * MB * HY];
+  const int UPR = (H + 1) / 2;                     // units per row
+  constexpr int NU = (MB * (HP / 2) + NTHREADS - 1) / NTHREADS;
+  int u_lds[NU], u_glb[NU], u_n[NU];               // tile offset (m * HY + e), row-relative global element offset, elements (0, 1, 2)
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const int q = threadIdx.x + NTHREADS * i;
+    const int m = q / UPR, e = 2 * (q % UPR);
+    const bool ok = q < MB * UPR && b0 + m < B;
+    u_lds[i] = ok ? m * HY + e : 0;
+    u_glb[i] = ok ? m * T * H + e : 0;
+    u_n[i] = ok ? (e + 1 < H ? 2 : 1) : 0;
+  }
   // wgnn_fwd_loss: the MSE statistics (sum of squares, max |Y - L|) are taken here, from the h this kernel
   // holds in registers, so no later pass re-reads Y and the labels for them
   const void* Labw = Lab ? (const char*)Lab + (size_t)b0 * T * H * esz : nullptr;
-  float lab[4] = {0.f, 0.f, 0.f, 0.f}, labn[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x2 lraw[NU];                                  // the next step's label units, in flight (raw bits when 16-bit)
+  auto load_lab = [&](int t) {
+    if (!Lab) return;
+    const int tc = t < T ? t : T - 1;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int o = u_glb[i] + tc * H;
+      if (io == 0) {
+        if (u_n[i] == 2) lraw[i] = *(const f32x2*)((const float*)Labw + o);
+        else if (u_n[i] == 1) lraw[i][0] = ((const float*)Labw)[o];
+      } else {
+        if (u_n[i] == 2) lraw[i][0] = __builtin_bit_cast(float, *(const unsigned*)((const unsigned short*)Labw + o));
+        else if (u_n[i] == 1) lraw[i][0] = __builtin_bit_cast(float, (unsigned)((const unsigned short*)Labw)[o]);
+      }
+    }
+  };
+  auto stage_lab = [&](int t) {                    // labels of step t -> ltile[t & 1] as fp32
+    if (!Lab) return;
+    float* lt = ltile + (t & 1) * MB * HY;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      if (u_n[i] == 0) continue;
+      f32x2 v = lraw[i];
+      if (io == 1) {
+        v = __builtin_convertvector(__builtin_bit_cast(h2v, __builtin_bit_cast(unsigned, lraw[i][0])), f32x2);
+      } else if (io == 2) {
+        const unsigned u = __builtin_bit_cast(unsigned, lraw[i][0]);
+        v[0] = __builtin_bit_cast(float, u << 16);
+        v[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+      }
+      lt[u_lds[i]] = v[0];
+      if (u_n[i] == 2) lt[u_lds[i] + 1] = v[1];
+    }
+  };
   float ssum = 0.f, smax = 0.f;
   float gi[3][4], gin[3][4];
-  auto load_gi = [&](int t, float (&dst)[3][4], float (&ldst)[4]) {
+  auto load_gi = [&](int t, float (&dst)[3][4]) {
     const int tc = t < T ? t : T - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -166,10 +223,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       dst[0][r] = GIw[o];
       dst[1][r] = GIw[o + H];
       dst[2][r] = GIw[o + 2 * H];
-      if (Lab) ldst[r] = io_load(Labw, (rowt[r] + tc) * H + jc, io);
     }
   };
-  load_gi(0, gi, lab);
+  load_lab(0);
+  stage_lab(0);
+  load_gi(0, gi);
   float hold[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
@@ -178,7 +236,10 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     const _Float16* hlo = hhi + MB * HS;
     _Float16* nhi = hbuf + ((t + 1) & 1) * 2 * MB * HS;          // h_t goes here
     _Float16* nlo = nhi + MB * HS;
-    load_gi(t + 1, gin, labn);                     // prefetch under this step's MFMAs
+    load_gi(t + 1, gin);                           // prefetch under this step's MFMAs
+    load_lab(t + 1);
+    float* yt = ytile + (t & 1) * MB * HY;
+    const float* lt = ltile + (t & 1) * MB * HY;
     float hnew[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
       f32x4 ar, az, an;
@@ -206,14 +267,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         const float ng = tanh_fast(gi[2][r] + rg * an[r]);
         rg4[r] = rg; zg4[r] = zg; ng4[r] = ng;
         hnew[r] = (1.f - zg) * ng + zg * hold[r];
-        if (rowok[r]) {
-          const int bt = rowt[r] + t;
-          io_store(Yw, bt * H + j, hnew[r], io);      // 16-bit I/O: rounded once, here; the statistics use hnew itself
-          if (Lab) {
-            const float dl = hnew[r] - lab[r];
-            ssum = fmaf(dl, dl, ssum);
-            smax = fmaxf(smax, fabsf(dl));
-          }
+        if (jv) yt[(4 * g + r) * HY + j] = hnew[r];     // -> Y through the row copy-out below
+        if (rowok[r] && Lab) {                          // the statistics use the unrounded h
+          const float dl = hnew[r] - lt[(4 * g + r) * HY + j];
+          ssum = fmaf(dl, dl, ssum);
+          smax = fmaxf(smax, fabsf(dl));
         }
         hold[r] = hnew[r];
       }
@@ -223,13 +281,40 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         rec[64] = zg4;
         rec[128] = ng4;
         rec[192] = an;
+        if (io) {
+          const f32x4 h4 = {hnew[0], hnew[1], hnew[2], hnew[3]};
+          rec[256] = h4;
+        }
       }
     }
     if (active && jv) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) put_split<X3>(nhi, nlo, (4 * g + r) * HS + j, hnew[r]);
     }
+    stage_lab(t + 1);                              // other parity than the labels read above
     __syncthreads();                               // h_t complete; everyone is done reading h_{t-1}
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {                 // row (b, t) of Y, 2 elements per thread, rounded once to the I/O type
+      if (u_n[i] == 0) continue;
+      const float v0 = yt[u_lds[i]], v1 = yt[u_lds[i] + 1];
+      const int o = u_glb[i] + t * H;
+      if (io == 0) {
+        if (u_n[i] == 2) { const f32x2 v = {v0, v1}; *(f32x2*)((float*)Yw + o) = v; }
+        else ((float*)Yw)[o] = v0;
+      } else {
+        unsigned pk;
+        if (io == 1) {
+          const f32x2 v = {v0, v1};
+          pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2v));
+        } else {
+          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+          const f32x2 v = {v0, v1};
+          pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+        }
+        if (u_n[i] == 2) *(unsigned*)((unsigned short*)Yw + o) = pk;
+        else ((unsigned short*)Yw)[o] = (unsigned short)pk;
+      }
+    }
     if (yp_hi) {   // h_t as fp16 planes (the B operand of the dW_hh GEMM): 16-byte chunks straight from LDS
       for (int q = threadIdx.x; q < (X3 ? 2 : 1) * MB * (HP / 8); q += NTHREADS) {
         const int plane = q / (MB * (HP / 8)), rem = q % (MB * (HP / 8));
@@ -245,8 +330,6 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r) gi[q][r] = gin[q][r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lab[r] = labn[r];
   }
   if (Lab) {   // block partials in a fixed order: lanes (xor tree), then the 8 waves
     __shared__ float red[2][NTHREADS / 64];
@@ -286,8 +369,6 @@ template <int KSB, bool X3>   // K steps of 32 over the padded dgh row: KSB = ce
 __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
                                                             const void* __restrict__ Y, const float* __restrict__ dY,
                                                             const void* __restrict__ Lab, int io,
-                                                            const _Float16* __restrict__ yp_hi,
-                                                            const _Float16* __restrict__ yp_lo, int hp_ld,
                                                             const float* __restrict__ gates,
                                                             const float* __restrict__ scales,
                                                             _Float16* __restrict__ dGI_hi, _Float16* __restrict__ dGI_lo,
@@ -325,21 +406,14 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     WT[ks] = split_vals(x);
   }
   const int NW = (H + 15) / 16;                              // gate stash: grux_fwd_kernel's register layout
-  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * GREC * 64 + lane;
-  // 16-bit I/O: Y on the wire is rounded, so h_{t-1} (and the Y of the fused dY) comes from the stash's h planes,
-  // hi + lo = the forward's fp32 h to 2^-22; explicit dY is always fp32, labels are io-typed
+  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * grec(io) * 64 + lane;
+  // 16-bit I/O: Y on the wire is rounded, so h_{t-1} (and the Y of the fused dY) is the 5th component of the stash
+  // records; explicit dY is always fp32; labels are io-typed and come in through LDS as whole rows (see grux_fwd_kernel)
   const int esz = io ? 2 : 4;
+  const int GREC = grec(io);
   const void* Labw = Lab ? (const char*)Lab + (size_t)b0 * T * H * esz : nullptr;
   const float* dYw = dY ? dY + (size_t)b0 * T * H : nullptr;
   const float* Yw = (const float*)Y + (size_t)b0 * T * H;
-  const _Float16* yph = yp_hi + (size_t)b0 * T * hp_ld;
-  const _Float16* ypl = yp_lo + (size_t)b0 * T * hp_ld;
-  auto load_h = [&](int bt) {     // h of row (b, t) = local row index bt
-    if (io == 0) return Yw[bt * H + jc];
-    float v = (float)yph[bt * hp_ld + jc];
-    if (X3) v += (float)ypl[bt * hp_ld + jc];
-    return v;
-  };
   int rowt[4];
   bool rowok[4];
 #pragma unroll
@@ -381,6 +455,52 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
       }
     }
   }
+  constexpr int HY = 32 * ((KSB * 32 / 3 + 31) / 32) + 34;     // >= H + 2 (H <= (32 KSB) / 3 + a few), even
+  __shared__ __attribute__((aligned(16))) float ltile[2 * MB * HY];
+  const int UPR = (H + 1) / 2;
+  constexpr int NU = (MB * (HY / 2) + NTHREADS - 1) / NTHREADS;
+  int u_lds[NU], u_glb[NU], u_n[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const int q = threadIdx.x + NTHREADS * i;
+    const int m = q / UPR, e = 2 * (q % UPR);
+    const bool ok = Lab && q < MB * UPR && b0 + m < B;
+    u_lds[i] = ok ? m * HY + e : 0;
+    u_glb[i] = ok ? m * T * H + e : 0;
+    u_n[i] = ok ? (e + 1 < H ? 2 : 1) : 0;
+  }
+  f32x2 lraw[NU];
+  auto load_lab = [&](int t) {
+    const int tc = t > 0 ? t : 0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int o = u_glb[i] + tc * H;
+      if (io == 0) {
+        if (u_n[i] == 2) lraw[i] = *(const f32x2*)((const float*)Labw + o);
+        else if (u_n[i] == 1) lraw[i][0] = ((const float*)Labw)[o];
+      } else {
+        if (u_n[i] == 2) lraw[i][0] = __builtin_bit_cast(float, *(const unsigned*)((const unsigned short*)Labw + o));
+        else if (u_n[i] == 1) lraw[i][0] = __builtin_bit_cast(float, (unsigned)((const unsigned short*)Labw)[o]);
+      }
+    }
+  };
+  auto stage_lab = [&](int t) {                    // labels of step t -> ltile[t & 1] as fp32
+    float* lt = ltile + (t & 1) * MB * HY;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      if (u_n[i] == 0) continue;
+      f32x2 v = lraw[i];
+      if (io == 1) {
+        v = __builtin_convertvector(__builtin_bit_cast(h2v, __builtin_bit_cast(unsigned, lraw[i][0])), f32x2);
+      } else if (io == 2) {
+        const unsigned u = __builtin_bit_cast(unsigned, lraw[i][0]);
+        v[0] = __builtin_bit_cast(float, u << 16);
+        v[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+      }
+      lt[u_lds[i]] = v[0];
+      if (u_n[i] == 2) lt[u_lds[i] + 1] = v[1];
+    }
+  };
   struct StepIn { float dy[4], r[4], z[4], n[4], ghn[4], hp[4]; };
   auto load_step = [&](int t, StepIn& s) {
     const int tc = t > 0 ? t : 0;
@@ -389,21 +509,34 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int bt = rowt[r] + tc;
-      s.dy[r] = Lab ? io_load(Labw, bt * H + jc, io) : dYw[bt * H + jc];
+      s.dy[r] = Lab ? 0.f : dYw[bt * H + jc];            // labels: read from ltile at the top of their step
       s.r[r] = r4[r];
       s.z[r] = z4[r];
       s.n[r] = n4[r];
       s.ghn[r] = g4[r];
-      const float hp = load_h(bt - (tc > 0 ? 1 : 0));
+      const float hp = io ? 0.f : Yw[(bt - (tc > 0 ? 1 : 0)) * H + jc];
       s.hp[r] = tc > 0 ? hp : 0.f;
+    }
+    if (io && tc > 0) {                                  // h_{t-1} = 5th component of step t-1's record
+      const f32x4 h4 = (gatesw + (size_t)(tc - 1) * NW * GREC * 64)[256];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s.hp[r] = h4[r];
     }
   };
   StepIn cur, nxt;
   load_step(T - 1, cur);
   float ycur[4] = {0.f, 0.f, 0.f, 0.f};
   if (Lab) {
+    if (io) {
+      const f32x4 h4 = (gatesw + (size_t)(T - 1) * NW * GREC * 64)[256];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ycur[r] = load_h(rowt[r] + T - 1);
+      for (int r = 0; r < 4; ++r) ycur[r] = h4[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ycur[r] = Yw[(rowt[r] + T - 1) * H + jc];
+    }
+    load_lab(T - 1);
+    stage_lab(T - 1);
   }
   f32x4 dhn = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
@@ -415,12 +548,14 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     _Float16* ihi = dbuf + 2 * MB * DS;
     _Float16* ilo = dbuf + 3 * MB * DS;
     load_step(t - 1, nxt);
+    if (Lab) load_lab(t - 1);
+    const float* lt = ltile + (t & 1) * MB * HY;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (active) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = 4 * g + r;
-        const float dyv = Lab ? (ycur[r] - cur.dy[r]) * coef : cur.dy[r];
+        const float dyv = Lab ? (ycur[r] - lt[m * HY + jc]) * coef : cur.dy[r];
         const float dh = rowok[r] ? dyv * s_in + dhn[r] : 0.f;
         const float rg = cur.r[r], zg = cur.z[r], ng = cur.n[r];
         const float dn = dh * (1.f - zg);
@@ -445,6 +580,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
         }
       }
     }
+    if (Lab) stage_lab(t - 1);          // other parity than the labels read above; visible after the barrier
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {   // planes out: rows (b, t) of dGI and of dGHn
@@ -476,7 +612,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 bool grux_shape_supported(int H) { return H >= 1 && H <= 127; }
 
 int grux_hp(int H) { return 32 * cdiv_i(H + 1, 32); }
-size_t grux_gates_floats(int B, int T, int H) { return (size_t)cdiv_i(B, MB) * T * cdiv_i(H, 16) * GREC * 64 * 4; }
+size_t grux_gates_floats(int B, int T, int H, int io) {
+  return (size_t)cdiv_i(B, MB) * T * cdiv_i(H, 16) * grec(io) * 64 * 4;
+}
 int grux_blocks(int B) { return cdiv_i(B, MB); }
 
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, void* Y,
@@ -488,7 +626,7 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H,
                by = bt * (4.0 * 3 * H + (io ? 2.0 : 4.0) * (H + (labels ? H : 0))) +
-                    (gates ? 4.0 * grux_gates_floats(B, T, H) : 0.0);
+                    (gates ? 4.0 * grux_gates_floats(B, T, H, io) : 0.0);
   const dim3 grid(cdiv_i(B, MB));
 #define FCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
@@ -515,11 +653,8 @@ int grux_hn(int H) { return 8 * cdiv_i(H, 8); }
 int grux_msplit(int H) { return 8 * cdiv_i(2 * H, 8); }
 
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
-                    const void* y_planes, const float* gates,
+                    const float* gates,
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st) {
-  const _Float16* yh = (const _Float16*)y_planes;
-  const _Float16* yl = yh + ((size_t)B * T + 1) * grux_hp(H);
-  const int hp_ld = grux_hp(H);
   _Float16* ih = (_Float16*)dGI_planes;
   _Float16* il = ih + (size_t)B * T * ldd;
   _Float16* nh = (_Float16*)dGHn_planes;
@@ -528,17 +663,17 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
   if (ldd % 8 != 0 || ldd < 3 * H || ldd > 32 * ksb) return WGNN_ERR_SHAPE;
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H,
-               by = bt * ((io ? 2.0 + 4.0 : 4.0 + 4.0) * H + 4.0 * (3 * H + H)) + 4.0 * grux_gates_floats(B, T, H);
+               by = bt * ((io ? 2.0 + 4.0 : 4.0 + 4.0) * H + 4.0 * (3 * H + H)) + 4.0 * grux_gates_floats(B, T, H, io);
   const dim3 grid(cdiv_i(B, MB));
 #define BCASE(K)                                                                                                   \
   if (x3)                                                                                                          \
     PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                             \
                 hipLaunchKernelGGL((grux_bwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
-                                   io, yh, yl, hp_ld, gates, scales, ih, il, ldd, nh, nl));                               \
+                                   io, gates, scales, ih, il, ldd, nh, nl));                                              \
   else                                                                                                             \
     PROF_LAUNCH("grux_bwd_kernel<" #K ",f16>", fl, by * 0.75, st,                                                  \
                 hipLaunchKernelGGL((grux_bwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
-                                   io, yh, yl, hp_ld, gates, scales, ih, il, ldd, nh, nl))
+                                   io, gates, scales, ih, il, ldd, nh, nl))
   switch (ksb) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;
