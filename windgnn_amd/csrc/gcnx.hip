@@ -213,7 +213,8 @@ __device__ __forceinline__ Frag xfrag_nat(const float* xb, int i, int c, int g) 
 
 constexpr int FWD_WAVES = 8;   // waves per forward block (A fragments are shared through LDS)
 
-template <int NT, bool X3>
+// IO: X is 16-bit (fp16 / bf16 by `io`); false = fp32 (no conversion code at all in the default instance)
+template <int NT, bool X3, bool IO>
 __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const void* __restrict__ X, int io, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
@@ -287,21 +288,21 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       if (64 * k < npairs) {       // wave-uniform
-        const f32x2 v = io_pair(xr[k], io);
+        const f32x2 v = IO ? io_pair(xr[k], io) : xr[k];
         xb[map.o0[k]] = v[0];
         xb[map.o1[k]] = v[1];
       }
     }
   };
   if (wave_id < ntiles) {
-    gload_pairs_io<NP>(xr, X, (size_t)wave_id * I, lane, I, io);
+    gload_pairs_io<NP>(xr, X, (size_t)wave_id * I, lane, I, IO ? io : 0);
     stage_x();
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     asm volatile("" ::: "memory");                    // keep the A-fragment reads in LDS (no hoisting into VGPRs)
     wave_lds_fence();                                 // this tile's X is staged
     const bool more = tile + nwaves < ntiles;
-    if (more) gload_pairs_io<NP>(xr, X, (size_t)(tile + nwaves) * I, lane, I, io);   // prefetch the next tile
+    if (more) gload_pairs_io<NP>(xr, X, (size_t)(tile + nwaves) * I, lane, I, IO ? io : 0);   // prefetch the next tile
 
     f32x4 U[NT];
 #pragma unroll
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 // three waves per SIMD (166 VGPRs) hide more of it than two (measured 181 vs 198 us; 4-wave blocks, 2 per CU).
 constexpr int bwd_waves(int NT) { return 12; }   // (16 waves at 128 VGPRs spill: 291 vs 181 us)
 
-template <int NT, bool X3>
+template <int NT, bool X3, bool IO>
 __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const void* __restrict__ X, int io, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
   f32x2 xr[NP], dr[NP];
   h2 gr[NP];
   if (wave_id < ntiles) {
-    gload_pairs_io<NP>(xr, X, (size_t)wave_id * I, lane, I, io);
+    gload_pairs_io<NP>(xr, X, (size_t)wave_id * I, lane, I, IO ? io : 0);
     gload_pairs_h<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
     gload_pairs<NP>(dr, dg + (size_t)wave_id * I, lane, I);
   }
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       if (64 * k < npairs) {       // wave-uniform; lanes past the tile write the dump slot
-        const f32x2 xv = io_pair(xr[k], io);
+        const f32x2 xv = IO ? io_pair(xr[k], io) : xr[k];
         xb[map.o0[k]] = xv[0];
         xb[map.o1[k]] = xv[1];
         db[map.o0[k]] = (float)gr[k][0] > 0.f ? dr[k][0] * s_in : 0.f;     // dZ2 = dg * (g > 0), range-scaled
@@ -484,7 +485,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
     wave_lds_fence();
     if (tile + nwaves < ntiles) {                               // prefetch the next tile under this one's math
       const size_t nt = (size_t)(tile + nwaves);
-      gload_pairs_io<NP>(xr, X, nt * I, lane, I, io);
+      gload_pairs_io<NP>(xr, X, nt * I, lane, I, IO ? io : 0);
       gload_pairs_h<NP>(gr, gact + nt * ld_g, lane, I);
       gload_pairs<NP>(dr, dg + nt * I, lane, I);
     }
@@ -628,15 +629,15 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, c
   int gx = cdiv_i(ntiles, FWD_WAVES);
   gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
   const dim3 grid(gx);
+#define FWD_LAUNCH(NT, X3V, IOV, NAME, BYTES)                                                                     \
+  PROF_LAUNCH(NAME, fl, BYTES, st,                                                                                \
+              hipLaunchKernelGGL((gcnx_fwd_kernel<NT, X3V, IOV>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, io, W1, \
+                                 b1, W2, b2, ghi, glo, ldg, status))
 #define FWD_CASE(NT)                                                                                              \
-  if (x3)                                                                                                         \
-    PROF_LAUNCH("gcnx_fwd_kernel<" #NT ">", fl, by, st,                                                           \
-                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, true>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, io, W1, b1, W2, b2, \
-                                   ghi, glo, ldg, status));                                                       \
-  else                                                                                                            \
-    PROF_LAUNCH("gcnx_fwd_kernel<" #NT ",f16>", fl, by * 0.75, st,                                                \
-                hipLaunchKernelGGL((gcnx_fwd_kernel<NT, false>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, io, W1, b1, W2, \
-                                   b2, ghi, glo, ldg, status))
+  if (x3 && !io) FWD_LAUNCH(NT, true, false, "gcnx_fwd_kernel<" #NT ">", by);                                     \
+  else if (x3) FWD_LAUNCH(NT, true, true, "gcnx_fwd_kernel<" #NT ">", by);                                        \
+  else if (!io) FWD_LAUNCH(NT, false, false, "gcnx_fwd_kernel<" #NT ",f16>", by * 0.75);                          \
+  else FWD_LAUNCH(NT, false, true, "gcnx_fwd_kernel<" #NT ",f16>", by * 0.75)
   switch ((S + 15) / 16) {
     case 1: FWD_CASE(1); break;
     case 2: FWD_CASE(2); break;
@@ -645,6 +646,7 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, c
     default: return WGNN_ERR_UNSUPPORTED;
   }
 #undef FWD_CASE
+#undef FWD_LAUNCH
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -657,15 +659,15 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
   // what the launch reads: X and dg as fp32, and the fp16 hi plane of g (2 bytes x ldg per tile) as the ReLU mask
   const double by = (double)ntiles * (S * 13 * (io ? 2.0 : 4.0) + S * 13 * 4.0 + ldg * 2.0);
   const dim3 grid(grid_x(ntiles, S));
-#define BWD_CASE(NT)                                                                                               \
-  if (x3)                                                                                                          \
-    PROF_LAUNCH("gcnx_bwd_kernel<" #NT ">", fl, by, st,                                                            \
-                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, true>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, io, W1, b1, W2, g,  \
-                                   ldg, dg, scales, scale_in, partial));                                           \
-  else                                                                                                             \
-    PROF_LAUNCH("gcnx_bwd_kernel<" #NT ",f16>", fl, by, st,                                                        \
-                hipLaunchKernelGGL((gcnx_bwd_kernel<NT, false>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, io, W1, b1, W2, g, \
-                                   ldg, dg, scales, scale_in, partial))
+#define BWD_LAUNCH(NT, X3V, IOV, NAME)                                                                            \
+  PROF_LAUNCH(NAME, fl, by, st,                                                                                   \
+              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, io, \
+                                 W1, b1, W2, g, ldg, dg, scales, scale_in, partial))
+#define BWD_CASE(NT)                                                                                              \
+  if (x3 && !io) BWD_LAUNCH(NT, true, false, "gcnx_bwd_kernel<" #NT ">");                                         \
+  else if (x3) BWD_LAUNCH(NT, true, true, "gcnx_bwd_kernel<" #NT ">");                                            \
+  else if (!io) BWD_LAUNCH(NT, false, false, "gcnx_bwd_kernel<" #NT ",f16>");                                     \
+  else BWD_LAUNCH(NT, false, true, "gcnx_bwd_kernel<" #NT ",f16>")
   switch ((S + 15) / 16) {
     case 1: BWD_CASE(1); break;
     case 2: BWD_CASE(2); break;
@@ -674,6 +676,7 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
     default: return WGNN_ERR_UNSUPPORTED;
   }
 #undef BWD_CASE
+#undef BWD_LAUNCH
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

@@ -88,7 +88,9 @@ __device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, f
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int KS, bool X3>   // K steps of 32 over the hidden index (+ the ones column): KS = ceil((H+1)/32)
+// IO: Y and the labels are 16-bit on the wire (fp16 / bf16 by `io`) and move through LDS as whole rows; the fp32
+// instance keeps the direct per-lane accesses (the row path was 30 % slower there: measured 116 vs 84 us).
+template <int KS, bool X3, bool IO>   // K steps of 32 over the hidden index (+ the ones column): KS = ceil((H+1)/32)
 __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const float* __restrict__ GI, int ldgi,
                                                             const float* __restrict__ Whh,
                                                             const float* __restrict__ bhh, void* __restrict__ Y,
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   // Addressing: one workgroup-uniform 64-bit base per array (the workgroup's first window) plus 32-bit lane
   // offsets.  Row indices are clamped so every load is unconditional.
   const float* GIw = GI + (size_t)b0 * T * ldgi;
-  const int esz = io ? 2 : 4;                      // bytes per element of Y and the labels (wgnn_io)
+  constexpr int esz = IO ? 2 : 4;                  // bytes per element of Y and the labels (wgnn_io)
   void* Yw = (char*)Y + (size_t)b0 * T * H * esz;
   // gate stash in this kernel's own register layout, [workgroup][t][wave][r | z | n | gh_n][lane] x float4 (the 4 window
   // rows a lane owns): one 16-byte store per lane and component (a full 1 KB per wave-instruction) instead of sixteen
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   // WRONG for trained weights -- saturated gates need r (1 - r) to fp32's own precision (8 % gradient error on the
   // wind_gnn_7.pth fixture).
   const int NW = (H + 15) / 16;
-  const int GREC = grec(io);
+  constexpr int GREC = IO ? 5 : 4;
   f32x4* gatesw = gates ? (f32x4*)gates + ((size_t)blockIdx.x * T * NW + wave) * GREC * 64 + lane : nullptr;
   int rowt[4];            // (local window row) * T, clamped to the last valid window
   bool rowok[4];
@@ -162,8 +164,8 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   // lane storing / loading single elements in 64-byte (32-byte at 16 bits) segments.  ytile / ltile are double-buffered
   // by step parity like hbuf.  Unit q = threadIdx.x + 512 i of the workgroup's 16 rows: fixed for the whole launch.
   constexpr int HY = HP + 2;                       // fp32 row stride of the tiles (even: 8-byte aligned pairs)
-  __shared__ __attribute__((aligned(16))) float ytile[2 * MB * HY];
-  __shared__ __attribute__((aligned(16))) float ltile[2 * MB * HY];
+  __shared__ __attribute__((aligned(16))) float ytile[IO ? 2 * MB * HY : 4];
+  __shared__ __attribute__((aligned(16))) float ltile[IO ? 2 * MB * HY : 4];
   const int UPR = (H + 1) / 2;                     // units per row
   constexpr int NU = (MB * (HP / 2) + NTHREADS - 1) / NTHREADS;
   int u_lds[NU], u_glb[NU], u_n[NU];               // tile offset (m * HY + e), row-relative global element offset, elements (0, 1, 2)
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   const void* Labw = Lab ? (const char*)Lab + (size_t)b0 * T * H * esz : nullptr;
   f32x2 lraw[NU];                                  // the next step's label units, in flight (raw bits when 16-bit)
   auto load_lab = [&](int t) {
-    if (!Lab) return;
+    if (!IO || !Lab) return;
     const int tc = t < T ? t : T - 1;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     }
   };
   auto stage_lab = [&](int t) {                    // labels of step t -> ltile[t & 1] as fp32
-    if (!Lab) return;
+    if (!IO || !Lab) return;
     float* lt = ltile + (t & 1) * MB * HY;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
@@ -214,8 +216,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     }
   };
   float ssum = 0.f, smax = 0.f;
+  float lab[4] = {0.f, 0.f, 0.f, 0.f}, labn[4] = {0.f, 0.f, 0.f, 0.f};   // fp32 I/O: the owner lanes load their labels
   float gi[3][4], gin[3][4];
-  auto load_gi = [&](int t, float (&dst)[3][4]) {
+  auto load_gi = [&](int t, float (&dst)[3][4], float (&ldst)[4]) {
     const int tc = t < T ? t : T - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -223,11 +226,12 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       dst[0][r] = GIw[o];
       dst[1][r] = GIw[o + H];
       dst[2][r] = GIw[o + 2 * H];
+      if (!IO && Lab) ldst[r] = ((const float*)Labw)[(rowt[r] + tc) * H + jc];
     }
   };
   load_lab(0);
   stage_lab(0);
-  load_gi(0, gi);
+  load_gi(0, gi, lab);
   float hold[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     const _Float16* hlo = hhi + MB * HS;
     _Float16* nhi = hbuf + ((t + 1) & 1) * 2 * MB * HS;          // h_t goes here
     _Float16* nlo = nhi + MB * HS;
-    load_gi(t + 1, gin);                           // prefetch under this step's MFMAs
+    load_gi(t + 1, gin, labn);                     // prefetch under this step's MFMAs
     load_lab(t + 1);
     float* yt = ytile + (t & 1) * MB * HY;
     const float* lt = ltile + (t & 1) * MB * HY;
@@ -267,9 +271,13 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         const float ng = tanh_fast(gi[2][r] + rg * an[r]);
         rg4[r] = rg; zg4[r] = zg; ng4[r] = ng;
         hnew[r] = (1.f - zg) * ng + zg * hold[r];
-        if (jv) yt[(4 * g + r) * HY + j] = hnew[r];     // -> Y through the row copy-out below
+        if (IO) {
+          if (jv) yt[(4 * g + r) * HY + j] = hnew[r];   // -> Y through the row copy-out below
+        } else if (rowok[r]) {
+          ((float*)Yw)[(rowt[r] + t) * H + j] = hnew[r];
+        }
         if (rowok[r] && Lab) {                          // the statistics use the unrounded h
-          const float dl = hnew[r] - lt[(4 * g + r) * HY + j];
+          const float dl = hnew[r] - (IO ? lt[(4 * g + r) * HY + j] : lab[r]);
           ssum = fmaf(dl, dl, ssum);
           smax = fmaxf(smax, fabsf(dl));
         }
@@ -281,7 +289,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         rec[64] = zg4;
         rec[128] = ng4;
         rec[192] = an;
-        if (io) {
+        if (IO) {
           const f32x4 h4 = {hnew[0], hnew[1], hnew[2], hnew[3]};
           rec[256] = h4;
         }
@@ -294,7 +302,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     stage_lab(t + 1);                              // other parity than the labels read above
     __syncthreads();                               // h_t complete; everyone is done reading h_{t-1}
 #pragma unroll
-    for (int i = 0; i < NU; ++i) {                 // row (b, t) of Y, 2 elements per thread, rounded once to the I/O type
+    for (int i = 0; i < (IO ? NU : 0); ++i) {      // row (b, t) of Y, 2 elements per thread, rounded once to the I/O type
       if (u_n[i] == 0) continue;
       const float v0 = yt[u_lds[i]], v1 = yt[u_lds[i] + 1];
       const int o = u_glb[i] + t * H;
@@ -330,6 +338,8 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
     for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int r = 0; r < 4; ++r) gi[q][r] = gin[q][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lab[r] = labn[r];
   }
   if (Lab) {   // block partials in a fixed order: lanes (xor tree), then the 8 waves
     __shared__ float red[2][NTHREADS / 64];
@@ -365,7 +375,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
 // dGHn = dnt*r, planes [B*T][HN] (dGH's r and z thirds equal dGI's: the dW_hh GEMM takes them from the dGI planes).
 // In LDS the dgh row is laid out [dar | daz | pad to MS = 8*ceil(2H/8) | dnr] so that the dnr block is 16-byte aligned
 // for the copy-out; the W_hh^T fragments' k index follows the same layout.
-template <int KSB, bool X3>   // K steps of 32 over the padded dgh row: KSB = ceil((MS + H) / 32)
+template <int KSB, bool X3, bool IO>   // K steps of 32 over the padded dgh row: KSB = ceil((MS + H) / 32); IO: as grux_fwd_kernel
 __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
                                                             const void* __restrict__ Y, const float* __restrict__ dY,
                                                             const void* __restrict__ Lab, int io,
@@ -406,11 +416,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     WT[ks] = split_vals(x);
   }
   const int NW = (H + 15) / 16;                              // gate stash: grux_fwd_kernel's register layout
-  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * grec(io) * 64 + lane;
+  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * (IO ? 5 : 4) * 64 + lane;
   // 16-bit I/O: Y on the wire is rounded, so h_{t-1} (and the Y of the fused dY) is the 5th component of the stash
   // records; explicit dY is always fp32; labels are io-typed and come in through LDS as whole rows (see grux_fwd_kernel)
-  const int esz = io ? 2 : 4;
-  const int GREC = grec(io);
+  constexpr int esz = IO ? 2 : 4;
+  constexpr int GREC = IO ? 5 : 4;
   const void* Labw = Lab ? (const char*)Lab + (size_t)b0 * T * H * esz : nullptr;
   const float* dYw = dY ? dY + (size_t)b0 * T * H : nullptr;
   const float* Yw = (const float*)Y + (size_t)b0 * T * H;
@@ -456,15 +466,15 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     }
   }
   constexpr int HY = 32 * ((KSB * 32 / 3 + 31) / 32) + 34;     // >= H + 2 (H <= (32 KSB) / 3 + a few), even
-  __shared__ __attribute__((aligned(16))) float ltile[2 * MB * HY];
+  __shared__ __attribute__((aligned(16))) float ltile[IO ? 2 * MB * HY : 4];
   const int UPR = (H + 1) / 2;
-  constexpr int NU = (MB * (HY / 2) + NTHREADS - 1) / NTHREADS;
+  constexpr int NU = IO ? (MB * (HY / 2) + NTHREADS - 1) / NTHREADS : 1;
   int u_lds[NU], u_glb[NU], u_n[NU];
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
     const int q = threadIdx.x + NTHREADS * i;
     const int m = q / UPR, e = 2 * (q % UPR);
-    const bool ok = Lab && q < MB * UPR && b0 + m < B;
+    const bool ok = IO && Lab && q < MB * UPR && b0 + m < B;
     u_lds[i] = ok ? m * HY + e : 0;
     u_glb[i] = ok ? m * T * H + e : 0;
     u_n[i] = ok ? (e + 1 < H ? 2 : 1) : 0;
@@ -509,15 +519,16 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int bt = rowt[r] + tc;
-      s.dy[r] = Lab ? 0.f : dYw[bt * H + jc];            // labels: read from ltile at the top of their step
+      // 16-bit labels are read from ltile at the top of their step; fp32 labels / dY by the owner lane
+      s.dy[r] = Lab ? (IO ? 0.f : ((const float*)Labw)[bt * H + jc]) : dYw[bt * H + jc];
       s.r[r] = r4[r];
       s.z[r] = z4[r];
       s.n[r] = n4[r];
       s.ghn[r] = g4[r];
-      const float hp = io ? 0.f : Yw[(bt - (tc > 0 ? 1 : 0)) * H + jc];
+      const float hp = IO ? 0.f : Yw[(bt - (tc > 0 ? 1 : 0)) * H + jc];
       s.hp[r] = tc > 0 ? hp : 0.f;
     }
-    if (io && tc > 0) {                                  // h_{t-1} = 5th component of step t-1's record
+    if (IO && tc > 0) {                                  // h_{t-1} = 5th component of step t-1's record
       const f32x4 h4 = (gatesw + (size_t)(tc - 1) * NW * GREC * 64)[256];
 #pragma unroll
       for (int r = 0; r < 4; ++r) s.hp[r] = h4[r];
@@ -527,7 +538,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   load_step(T - 1, cur);
   float ycur[4] = {0.f, 0.f, 0.f, 0.f};
   if (Lab) {
-    if (io) {
+    if (IO) {
       const f32x4 h4 = (gatesw + (size_t)(T - 1) * NW * GREC * 64)[256];
 #pragma unroll
       for (int r = 0; r < 4; ++r) ycur[r] = h4[r];
@@ -535,8 +546,10 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
 #pragma unroll
       for (int r = 0; r < 4; ++r) ycur[r] = Yw[(rowt[r] + T - 1) * H + jc];
     }
-    load_lab(T - 1);
-    stage_lab(T - 1);
+    if (IO) {
+      load_lab(T - 1);
+      stage_lab(T - 1);
+    }
   }
   f32x4 dhn = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
@@ -548,14 +561,14 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     _Float16* ihi = dbuf + 2 * MB * DS;
     _Float16* ilo = dbuf + 3 * MB * DS;
     load_step(t - 1, nxt);
-    if (Lab) load_lab(t - 1);
+    if (IO && Lab) load_lab(t - 1);
     const float* lt = ltile + (t & 1) * MB * HY;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (active) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = 4 * g + r;
-        const float dyv = Lab ? (ycur[r] - lt[m * HY + jc]) * coef : cur.dy[r];
+        const float dyv = Lab ? (ycur[r] - (IO ? lt[m * HY + jc] : cur.dy[r])) * coef : cur.dy[r];
         const float dh = rowok[r] ? dyv * s_in + dhn[r] : 0.f;
         const float rg = cur.r[r], zg = cur.z[r], ng = cur.n[r];
         const float dn = dh * (1.f - zg);
@@ -580,7 +593,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
         }
       }
     }
-    if (Lab) stage_lab(t - 1);          // other parity than the labels read above; visible after the barrier
+    if (IO && Lab) stage_lab(t - 1);    // other parity than the labels read above; visible after the barrier
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {   // planes out: rows (b, t) of dGI and of dGHn
@@ -628,15 +641,15 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
                by = bt * (4.0 * 3 * H + (io ? 2.0 : 4.0) * (H + (labels ? H : 0))) +
                     (gates ? 4.0 * grux_gates_floats(B, T, H, io) : 0.0);
   const dim3 grid(cdiv_i(B, MB));
+#define FLAUNCH(K, X3V, IOV, NAME)                                                                                 \
+  PROF_LAUNCH(NAME, fl, by, st,                                                                                    \
+              hipLaunchKernelGGL((grux_fwd_kernel<K, X3V, IOV>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, Y, \
+                                 gates, yh, yl, status, labels, stat_part, io))
 #define FCASE(K)                                                                                                   \
-  if (x3)                                                                                                          \
-    PROF_LAUNCH("grux_fwd_kernel<" #K ">", fl, by, st,                                                             \
-                hipLaunchKernelGGL((grux_fwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, \
-                                   Y, gates, yh, yl, status, labels, stat_part, io));                              \
-  else                                                                                                             \
-    PROF_LAUNCH("grux_fwd_kernel<" #K ",f16>", fl, by, st,                                                         \
-                hipLaunchKernelGGL((grux_fwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh,    \
-                                   bhh, Y, gates, yh, yl, status, labels, stat_part, io))
+  if (x3 && !io) FLAUNCH(K, true, false, "grux_fwd_kernel<" #K ">");                                               \
+  else if (x3) FLAUNCH(K, true, true, "grux_fwd_kernel<" #K ">");                                                  \
+  else if (!io) FLAUNCH(K, false, false, "grux_fwd_kernel<" #K ",f16>");                                           \
+  else FLAUNCH(K, false, true, "grux_fwd_kernel<" #K ",f16>")
   switch (cdiv_i(H + 1, 32)) {
     case 1: FCASE(1); break;
     case 2: FCASE(2); break;
@@ -645,6 +658,7 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
     default: return WGNN_ERR_UNSUPPORTED;
   }
 #undef FCASE
+#undef FLAUNCH
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -665,15 +679,15 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
   const double fl = bt * 2.0 * 3 * H * H,
                by = bt * ((io ? 2.0 + 4.0 : 4.0 + 4.0) * H + 4.0 * (3 * H + H)) + 4.0 * grux_gates_floats(B, T, H, io);
   const dim3 grid(cdiv_i(B, MB));
-#define BCASE(K)                                                                                                   \
-  if (x3)                                                                                                          \
-    PROF_LAUNCH("grux_bwd_kernel<" #K ">", fl, by, st,                                                             \
-                hipLaunchKernelGGL((grux_bwd_kernel<K, true>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
-                                   io, gates, scales, ih, il, ldd, nh, nl));                                              \
-  else                                                                                                             \
-    PROF_LAUNCH("grux_bwd_kernel<" #K ",f16>", fl, by * 0.75, st,                                                  \
-                hipLaunchKernelGGL((grux_bwd_kernel<K, false>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, \
-                                   io, gates, scales, ih, il, ldd, nh, nl))
+#define BLAUNCH(K, X3V, IOV, NAME, BYTES)                                                                         \
+  PROF_LAUNCH(NAME, fl, BYTES, st,                                                                                \
+              hipLaunchKernelGGL((grux_bwd_kernel<K, X3V, IOV>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, io, \
+                                 gates, scales, ih, il, ldd, nh, nl))
+#define BCASE(K)                                                                                                  \
+  if (x3 && !io) BLAUNCH(K, true, false, "grux_bwd_kernel<" #K ">", by);                                          \
+  else if (x3) BLAUNCH(K, true, true, "grux_bwd_kernel<" #K ">", by);                                             \
+  else if (!io) BLAUNCH(K, false, false, "grux_bwd_kernel<" #K ",f16>", by * 0.75);                               \
+  else BLAUNCH(K, false, true, "grux_bwd_kernel<" #K ",f16>", by * 0.75)
   switch (ksb) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;
@@ -690,6 +704,7 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
     default: return WGNN_ERR_UNSUPPORTED;
   }
 #undef BCASE
+#undef BLAUNCH
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
