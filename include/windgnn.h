@@ -144,6 +144,13 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const void* X /* d->io */, cons
 int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* labels,
                   void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream);
 
+/* N4, the evaluation loop's read-out (src/main.py:100-103,116,131,146) as ONE call: forward without a stash, and
+ * out[b][j] = Y[b][T-1][j] * (wind_max - wind_min) + wind_min, [B, H] fp32.  With the register-resident recurrence
+ * (f16x3 / f16, H <= 127) the other T-1 rows of Y are never written; the other recurrences write Y into the workspace
+ * and read the last row out.  fp32 I/O only. */
+int wgnn_fwd_last(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, float wind_min,
+                  float wind_max, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Gradients of sum(Y * dY) w.r.t. the 8 parameters (overwritten, not accumulated).
  * No dX and no dA: neither requires grad in the reference (src/main.py:26,
  * src/step4_sequence_preparer.py:58). */

@@ -806,3 +806,44 @@ def test_full_size_B4096_with_16bit_io(math, iodt):
     assert abs(ln - float(loss_o)) <= (2e-3 if math == "f16" else 1e-5) * max(1.0, float(loss_o))
     for k, gk in zip(PARAM_KEYS, Gn):
         assert rel_to_max(gk.cpu(), go[k]) <= g_tol, k
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("fixture", ["f2_s7_t12_b32_ckpt", "f4_s34_t168_b1_ckpt"])
+def test_forward_last_is_the_evaluation_readout_in_one_call(fixture, math):
+    """N4 (src/main.py:100-103,116): wgnn_fwd_last = forward without a stash + last row * (max - min) + min, against the
+    reference's own Y (golden) and against the two-call route (forward, then wgnn_predict_last)."""
+    from windgnn_amd.data import forward_last, predict_last
+    dev = _dev()
+    fx = load_fixture(fixture)
+    S, H = fx["A"].shape[0], fx["Y"].shape[-1]
+    model = _model_from(fx["params"], S, H, math)
+    A, X = torch.from_numpy(fx["A"]).to(dev), torch.from_numpy(fx["X"]).to(dev)
+    wmin, wmax = 1.5, 87.5
+    out = forward_last(model, A, X, wmin, wmax)
+    ref = torch.from_numpy(fx["Y"])[:, -1, :] * (wmax - wmin) + wmin
+    tol = (Y_TOL if math != "f16" else F16_Y_TOL) * (wmax - wmin)
+    assert tuple(out.shape) == ((H,) if X.shape[0] == 1 else (X.shape[0], H))
+    assert max_abs(out.cpu().reshape(ref.shape), ref) <= tol
+    with torch.no_grad():
+        two = predict_last(model(A, X), wmin, wmax)
+    assert max_abs(out.reshape(two.shape).cpu(), two.cpu()) <= 1e-5 * (wmax - wmin)
+
+
+def test_forward_last_on_the_general_paths():
+    """wide GRU (per-step GEMM recurrence) and CSR adjacency: Y goes through the workspace, same read-out."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.data import forward_last
+    from windgnn_amd.graph import CsrAdjacency
+    dev = _dev()
+    S, T, B, H = 20, 5, 6, 200
+    g = torch.Generator().manual_seed(5)
+    A = torch.rand(S, S, generator=g) / S + 0.01
+    X = torch.rand(B, T, S, 13, generator=g)
+    p = orc.init_params(S, 13, H, seed=H)
+    Yo, _ = orc.forward(A.double(), X.double(), {k: v.double() for k, v in p.items()}, want_cache=False)
+    ref = Yo[:, -1, :] * 10.0 + 2.0
+    for math in ("f32", "f16x3"):
+        model = _model_from(p, S, H, math)
+        assert max_abs(forward_last(model, A.to(dev), X.to(dev), 2.0, 12.0).cpu(), ref) <= Y_TOL * 10.0
+        assert max_abs(forward_last(model, CsrAdjacency.from_dense(A).to(dev), X.to(dev), 2.0, 12.0).cpu(), ref) <= Y_TOL * 10.0

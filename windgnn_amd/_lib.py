@@ -42,6 +42,8 @@ EXPORTS = {
                            C.c_void_p, C.c_size_t, C.c_void_p]),
     "wgnn_fwd_loss": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wgnn_fwd_last": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_float, C.c_float,
+                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "wgnn_bwd": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                            C.c_void_p, C.POINTER(Grads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "wgnn_bwd_part": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,

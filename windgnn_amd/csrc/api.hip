@@ -11,7 +11,7 @@ struct Layout {
   size_t BT, I, Ip, G3, Gp, H, Hp;
   int np_g3, np_i;                 // padded plane rows of the two split-weight images (f16x3)
   // forward workspace (float offsets)
-  size_t ws_GI, ws_g, ws_planes_f, fwd_floats;
+  size_t ws_GI, ws_g, ws_planes_f, ws_Ylast, fwd_floats;
   // stash
   size_t st_g, st_gates, st_yp, stash_floats;
   // backward workspace
@@ -66,6 +66,7 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_hhp_f = o; o += al(L.gen_gru && x3 ? (size_t)L.np_g3 * L.Hp : 0);    // split(W_hh | b_hh)
   L.ws_kp_f = o; o += al(L.gen_gru && x3 ? pgemm_nt_kpart_floats(d->B, (int)L.Gp, (int)L.Hp) : 0);
   L.ws_hc = o; o += al(L.gen_gru && x3 ? (size_t)d->B * L.Hp : 0);          // compact planes of h_{t-1}
+  L.ws_Ylast = o; o += al((x3 && !L.gen_gru) ? 0 : L.BT * L.H);             // wgnn_fwd_last where the recurrence writes all of Y
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
@@ -176,11 +177,14 @@ size_t wgnn_stash_bytes(const wgnn_dims* d) {
   return sizeof(float) * make_layout(d).stash_floats;
 }
 
+// last != nullptr (wgnn_fwd_last): no stash; last[B][H] = Y[:, T-1, :] * y_mul + y_add and Y itself is only written
+// where the kernels cannot skip it (into the workspace, for the exact-fp32 and general-shape recurrences).
 static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* labels,
-                    void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream) {
+                    void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream, float* last = nullptr,
+                    float y_mul = 1.f, float y_add = 0.f) {
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
-  if (!A || !X || !p || !Y || !workspace) return WGNN_ERR_NULL;
+  if (!A || !X || !p || (!Y && !last) || !workspace) return WGNN_ERR_NULL;
   if (!p->conv1_weight || !p->conv1_bias || !p->conv2_weight || !p->conv2_bias || !p->w_ih || !p->w_hh ||
       !p->b_ih || !p->b_hh)
     return WGNN_ERR_NULL;
@@ -188,6 +192,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   if (workspace_bytes < sizeof(float) * L.fwd_floats) return WGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
+  if (last && !(L.x3 && !L.gen_gru)) Y = ws + L.ws_Ylast;   // these recurrences write every row: then read the last one out
   unsigned* status = (unsigned*)workspace;           // word 0 of the status block (include/windgnn.h)
   float* sf = (float*)stash;
   float* GI = ws + L.ws_GI;
@@ -217,13 +222,18 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
       rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 0, p->b_hh, (int)L.H, ws + L.ws_hhp_f, L.np_g3, (int)L.Hp,
                                 status, st);
       if (rc != WGNN_OK) return rc;
-      return launch_gru_gen_fwd_x3(d->B, d->T, d->H, GI, (int)L.Gp, ws + L.ws_hhp_f, L.np_g3, p->b_hh, (float*)Y, gates,
-                                   sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, ws + L.ws_kp_f, ws + L.ws_hc, full,
-                                   st);
+      rc = launch_gru_gen_fwd_x3(d->B, d->T, d->H, GI, (int)L.Gp, ws + L.ws_hhp_f, L.np_g3, p->b_hh, (float*)Y, gates,
+                                 sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, ws + L.ws_kp_f, ws + L.ws_hc, full,
+                                 st);
+      if (rc != WGNN_OK || !last) return rc;
+      return wgnn_predict_last((const float*)Y, d->B, d->T, d->H, y_add, y_add + y_mul, last, stream);
     }
+    if (last)   // the register-resident recurrence writes the read-out itself
+      return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, last, nullptr, nullptr, full, status,
+                             nullptr, nullptr, 0, 1, y_mul, y_add, st);
     // labels (wgnn_fwd_loss): the recurrence also leaves the MSE partial sums / maxima of (Y - labels) in the stash
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
-                           full, status, sf ? labels : nullptr, sf ? sf + L.st_stats : nullptr, d->io, st);
+                           full, status, sf ? labels : nullptr, sf ? sf + L.st_stats : nullptr, d->io, 0, 1.f, 0.f, st);
   }
   if (L.gen_gcn) {
     float* h1 = sf ? sf + L.st_h1 : ws + L.ws_h1;    // layer-1 activations: kept for the backward if there is a stash
@@ -242,8 +252,13 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   rc = launch_gemm_f32(ga, st);
   if (rc != WGNN_OK) return rc;
   if (L.gen_gru)
-    return launch_gru_gen_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, ws + L.ws_gh, st);
-  return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, st);
+    rc = launch_gru_gen_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, ws + L.ws_gh, st);
+  else if (gru_small_supported(d->B, d->H))   // few windows: one per workgroup instead of sixteen
+    rc = launch_gru_small_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, st);
+  else
+    rc = launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, st);
+  if (rc != WGNN_OK || !last) return rc;
+  return wgnn_predict_last((const float*)Y, d->B, d->T, d->H, y_add, y_add + y_mul, last, stream);
 }
 
 int wgnn_fwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, void* Y, void* stash,
@@ -255,6 +270,14 @@ int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const void* X, const wgnn_
                   void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream) {
   if (!labels || !stash) return WGNN_ERR_NULL;
   return fwd_impl(d, A, X, p, labels, Y, stash, workspace, workspace_bytes, stream);
+}
+
+int wgnn_fwd_last(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, float wind_min,
+                  float wind_max, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out) return WGNN_ERR_NULL;
+  if (d && d->io != WGNN_IO_F32) return WGNN_ERR_UNSUPPORTED;
+  return fwd_impl(d, A, X, p, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, out, wind_max - wind_min,
+                  wind_min);
 }
 
 int wgnn_bwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* Y,
@@ -386,6 +409,8 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     if (L.gen_gru)
       rc = launch_gru_gen_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, ws + L.ws_dhz,
                               ws + L.ws_dhw, st);
+    else if (gru_small_supported(d->B, d->H))
+      rc = launch_gru_small_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
     else
       rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
     if (rc != WGNN_OK) return rc;

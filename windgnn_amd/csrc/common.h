@@ -108,7 +108,7 @@ int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
 size_t grux_gates_floats(int B, int T, int H, int io);   // gate stash of the register-resident recurrences (their own layout)
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, void* Y,
                     float* gates, void* y_planes, bool x3, unsigned* status, const void* labels, float* stat_part,
-                    int io /*wgnn_io of Y and labels*/, hipStream_t st);
+                    int io /*wgnn_io of Y and labels*/, int last_only, float y_mul, float y_add, hipStream_t st);
 int grux_blocks(int B);   // workgroups of launch_grux_fwd = MSE partial pairs it writes when given labels
 // loss and scales {2^k, 2^-k, 2 grad_scale / n} from nblk partial pairs (sum | max) already computed
 int launch_mse_stats_finalize(const float* part, int nblk, int64_t n, float grad_scale, float* loss, float* scales,
@@ -193,6 +193,12 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* 
 int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY,
                    const float* gates, float* dGI, float* dGH, int ldd, hipStream_t st);
 bool gru_shape_supported(int H);
+// small batches (B <= 2048, H <= 128), exact fp32, one to four windows per workgroup with W_hh in registers (gru_small.hip)
+bool gru_small_supported(int B, int H);
+int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                         float* gates, hipStream_t st);
+int launch_gru_small_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
+                         float* dGI, float* dGH, int ldd, hipStream_t st);
 
 int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY, float* loss,
                float* ws, hipStream_t st);

@@ -1,0 +1,274 @@
+// GRU recurrence for SMALL batches, exact fp32: one to four windows per workgroup, W_hh in REGISTERS.
+//
+// Reference: nn.GRU (1 layer, batch_first, h0 = 0, gates r,z,n) at src/step6_gcn_gru_combined_model.py:11,23 and
+// its BPTT (src/main.py:79) -- the same equations as gru.hip.
+//
+// gru.hip gives a workgroup 16 windows (one MFMA M tile): at BASELINE configs[1] (B = 256) that is 16 workgroups on
+// 256 CUs, and the launch lasts as long as ONE workgroup's 24 dependent steps (126 / 163 us forward / backward).
+// Here a workgroup owns WPB <= 4 windows, thread i owns gate row i of W_hh (forward: the row itself, 4H bytes of
+// registers; backward: column j of gate block q, i = q H + j) and the per-step matrix-vector products are plain fp32
+// FMA chains against h / dgh broadcast from LDS: no MFMA tile to fill, ~B workgroups instead of B/16, and a step costs
+// ~H FMAs per thread.  Used when B <= 2048; results are fp32 fmaf chains like gru.hip's (different summation order).
+#include "common.h"
+
+namespace {
+
+constexpr int SMALL_THREADS = 384;   // >= 3 * HMAX for HMAX <= 128
+
+// ------------------------------------------------------------------------------------------------
+template <int HMAX, int WPB>
+__global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int T, int H,
+                                                                      const float* __restrict__ GI, int ldgi,
+                                                                      const float* __restrict__ Whh,
+                                                                      const float* __restrict__ bhh,
+                                                                      float* __restrict__ Y, float* __restrict__ gates) {
+  __shared__ __attribute__((aligned(16))) float hs[WPB][HMAX];       // h_{t-1}, zero beyond H
+  __shared__ float ghs[WPB][3 * HMAX];                               // W_hh h + b_hh, gate-major with stride HMAX
+  const int i = threadIdx.x;
+  const int G3 = 3 * H;
+  const bool iv = i < G3;
+  const int ic = iv ? i : G3 - 1;
+  const int q = ic / H, jq = ic % H;                                  // gate and unit of this thread's row
+  float w[HMAX];
+#pragma unroll
+  for (int k = 0; k < HMAX; ++k) w[k] = k < H ? Whh[(size_t)ic * H + k] : 0.f;
+  const float bh = bhh[ic];
+  const int b0 = blockIdx.x * WPB;
+  for (int k = threadIdx.x; k < WPB * HMAX; k += blockDim.x) (&hs[0][0])[k] = 0.f;
+  // gate phase: thread j < H owns hidden unit j of every window of the workgroup
+  const int j = threadIdx.x;
+  const bool jv = j < H;
+  const int jc = jv ? j : H - 1;
+  float gi[WPB][3], gin[WPB][3];
+  auto load_gi = [&](int t, float (&dst)[WPB][3]) {
+    const int tc = t < T ? t : T - 1;
+#pragma unroll
+    for (int wdw = 0; wdw < WPB; ++wdw) {
+      const int b = b0 + wdw < B ? b0 + wdw : B - 1;
+      const float* row = GI + ((size_t)b * T + tc) * ldgi;
+      dst[wdw][0] = row[jc];
+      dst[wdw][1] = row[H + jc];
+      dst[wdw][2] = row[2 * H + jc];
+    }
+  };
+  load_gi(0, gi);
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    load_gi(t + 1, gin);                            // next step's input projection, in flight under this step
+    float acc[WPB];
+#pragma unroll
+    for (int wdw = 0; wdw < WPB; ++wdw) acc[wdw] = bh;
+#pragma unroll
+    for (int k4 = 0; k4 < HMAX / 4; ++k4) {
+#pragma unroll
+      for (int wdw = 0; wdw < WPB; ++wdw) {
+        const f32x4 hv = *(const f32x4*)&hs[wdw][4 * k4];          // same address in every lane: LDS broadcast
+        acc[wdw] = fmaf(w[4 * k4 + 0], hv[0], acc[wdw]);
+        acc[wdw] = fmaf(w[4 * k4 + 1], hv[1], acc[wdw]);
+        acc[wdw] = fmaf(w[4 * k4 + 2], hv[2], acc[wdw]);
+        acc[wdw] = fmaf(w[4 * k4 + 3], hv[3], acc[wdw]);
+      }
+    }
+    if (iv) {
+#pragma unroll
+      for (int wdw = 0; wdw < WPB; ++wdw) ghs[wdw][q * HMAX + jq] = acc[wdw];
+    }
+    __syncthreads();                                // gh complete; every read of h_{t-1} is done
+    if (jv) {
+#pragma unroll
+      for (int wdw = 0; wdw < WPB; ++wdw) {
+        const int b = b0 + wdw;
+        const float ghn = ghs[wdw][2 * HMAX + j];
+        const float rg = sigmoidf_(gi[wdw][0] + ghs[wdw][j]);
+        const float zg = sigmoidf_(gi[wdw][1] + ghs[wdw][HMAX + j]);
+        const float ng = tanhf_(gi[wdw][2] + rg * ghn);
+        const float hnew = (1.f - zg) * ng + zg * hs[wdw][j];
+        hs[wdw][j] = hnew;
+        if (b < B) {
+          const size_t bt = (size_t)b * T + t;
+          Y[bt * H + j] = hnew;
+          if (gates) {
+            float* gp = gates + bt * 4 * H;
+            gp[j] = rg;
+            gp[H + j] = zg;
+            gp[2 * H + j] = ng;
+            gp[3 * H + j] = ghn;
+          }
+        }
+      }
+    }
+    __syncthreads();                                // h_t in place
+#pragma unroll
+    for (int wdw = 0; wdw < WPB; ++wdw)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gi[wdw][c] = gin[wdw][c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BPTT.  Per step (t descending), with dh = dY_t + dh_next:
+//   dn = dh (1-z), dz = dh (hprev - n), dnt = dn (1-n^2), dr = dnt gh_n,
+//   dar = dr r (1-r), daz = dz z (1-z);  dgi = [dar, daz, dnt], dgh = [dar, daz, dnt r]
+//   dh_next = dh z + dgh W_hh                       (thread (q, j): sum over gate block q of dgh[q][k] W_hh[qH+k][j])
+template <int HMAX, int WPB>
+__global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int T, int H,
+                                                                      const float* __restrict__ Whh,
+                                                                      const float* __restrict__ Y,
+                                                                      const float* __restrict__ dY,
+                                                                      const float* __restrict__ gates,
+                                                                      float* __restrict__ dGI, float* __restrict__ dGH,
+                                                                      int ldd) {
+  __shared__ __attribute__((aligned(16))) float dghs[WPB][3 * HMAX];  // dgh_t, gate-major with stride HMAX, zero pads
+  __shared__ float part[WPB][3][HMAX];                                 // the three gate blocks' shares of dgh W_hh
+  const int i = threadIdx.x;
+  const int G3 = 3 * H;
+  const bool iv = i < G3;
+  const int ic = iv ? i : G3 - 1;
+  const int q = ic / H, j = ic % H;
+  float wT[HMAX];                                                      // W_hh[qH + k][j], k < H
+#pragma unroll
+  for (int k = 0; k < HMAX; ++k) wT[k] = k < H ? Whh[(size_t)(q * H + k) * H + j] : 0.f;
+  const int b0 = blockIdx.x * WPB;
+  for (int k = threadIdx.x; k < WPB * 3 * HMAX; k += blockDim.x) (&dghs[0][0])[k] = 0.f;
+  {  // zero the K-padding columns [3H, ldd) of this workgroup's dGI / dGH rows
+    const int npad = ldd - G3;
+    const int nrows = min(WPB, B - b0) * T;
+    for (int e = threadIdx.x; e < nrows * npad; e += blockDim.x) {
+      const size_t o = ((size_t)b0 * T + e / npad) * ldd + G3 + e % npad;
+      dGI[o] = 0.f;
+      dGH[o] = 0.f;
+    }
+  }
+  const bool own = i < H;                                             // gate-phase owner of unit i (then q == 0, j == i)
+  struct StepIn { float dy, r, z, n, ghn, hp; };
+  StepIn cur[WPB], nxt[WPB];
+  auto load_step = [&](int t, StepIn (&s)[WPB]) {
+    const int tc = t > 0 ? t : 0;
+    if (!own) return;                               // only the H gate-phase owners need a step's inputs
+#pragma unroll
+    for (int wdw = 0; wdw < WPB; ++wdw) {
+      const int b = b0 + wdw < B ? b0 + wdw : B - 1;
+      const size_t bt = (size_t)b * T + tc;
+      const float* gp = gates + bt * 4 * H;
+      const int jj = i;
+      s[wdw].dy = dY[bt * H + jj];
+      s[wdw].r = gp[jj];
+      s[wdw].z = gp[H + jj];
+      s[wdw].n = gp[2 * H + jj];
+      s[wdw].ghn = gp[3 * H + jj];
+      const float hp = Y[(bt - (tc > 0 ? 1 : 0)) * H + jj];
+      s[wdw].hp = tc > 0 ? hp : 0.f;
+    }
+  };
+  load_step(T - 1, cur);
+  float dhn[WPB], dhz[WPB];
+#pragma unroll
+  for (int wdw = 0; wdw < WPB; ++wdw) dhn[wdw] = 0.f;
+  __syncthreads();
+
+  for (int t = T - 1; t >= 0; --t) {
+    load_step(t - 1, nxt);
+    if (own) {
+#pragma unroll
+      for (int wdw = 0; wdw < WPB; ++wdw) {
+        const int b = b0 + wdw;
+        const float dh = cur[wdw].dy + dhn[wdw];
+        const float rg = cur[wdw].r, zg = cur[wdw].z, ng = cur[wdw].n;
+        const float dn = dh * (1.f - zg);
+        const float dz = dh * (cur[wdw].hp - ng);
+        const float dnt = dn * (1.f - ng * ng);
+        const float dr = dnt * cur[wdw].ghn;
+        const float dar = dr * rg * (1.f - rg);
+        const float daz = dz * zg * (1.f - zg);
+        const float dnr = dnt * rg;
+        dhz[wdw] = dh * zg;
+        const bool ok = b < B;
+        dghs[wdw][i] = ok ? dar : 0.f;
+        dghs[wdw][HMAX + i] = ok ? daz : 0.f;
+        dghs[wdw][2 * HMAX + i] = ok ? dnr : 0.f;
+        if (ok) {
+          const size_t bt = (size_t)b * T + t;
+          float* gi = dGI + bt * ldd;
+          float* gh = dGH + bt * ldd;
+          gi[i] = dar; gi[H + i] = daz; gi[2 * H + i] = dnt;
+          gh[i] = dar; gh[H + i] = daz; gh[2 * H + i] = dnr;
+        }
+      }
+    }
+    __syncthreads();
+    if (t > 0) {
+      float p[WPB];
+#pragma unroll
+      for (int wdw = 0; wdw < WPB; ++wdw) p[wdw] = 0.f;
+#pragma unroll
+      for (int k4 = 0; k4 < HMAX / 4; ++k4) {
+#pragma unroll
+        for (int wdw = 0; wdw < WPB; ++wdw) {
+          const f32x4 dv = *(const f32x4*)&dghs[wdw][q * HMAX + 4 * k4];
+          p[wdw] = fmaf(dv[0], wT[4 * k4 + 0], p[wdw]);
+          p[wdw] = fmaf(dv[1], wT[4 * k4 + 1], p[wdw]);
+          p[wdw] = fmaf(dv[2], wT[4 * k4 + 2], p[wdw]);
+          p[wdw] = fmaf(dv[3], wT[4 * k4 + 3], p[wdw]);
+        }
+      }
+      if (iv) {
+#pragma unroll
+        for (int wdw = 0; wdw < WPB; ++wdw) part[wdw][q][j] = p[wdw];
+      }
+    }
+    __syncthreads();
+    if (own && t > 0) {
+#pragma unroll
+      for (int wdw = 0; wdw < WPB; ++wdw)
+        dhn[wdw] = dhz[wdw] + ((part[wdw][0][i] + part[wdw][1][i]) + part[wdw][2][i]);
+    }
+#pragma unroll
+    for (int wdw = 0; wdw < WPB; ++wdw) cur[wdw] = nxt[wdw];
+  }
+}
+
+int pick_wpb(int B) { return B <= 512 ? 1 : (B <= 1024 ? 2 : 4); }
+
+}  // namespace
+
+bool gru_small_supported(int B, int H) { return H >= 1 && H <= 128 && B <= 2048; }
+
+#define SMALL_DISPATCH(KERNEL, ...)                                                                              \
+  do {                                                                                                           \
+    const int wpb = pick_wpb(B);                                                                                 \
+    const dim3 grid(cdiv_i(B, wpb)), block(cdiv_i(3 * H, 64) * 64);                                              \
+    const int hm = H <= 32 ? 32 : (H <= 64 ? 64 : (H <= 96 ? 96 : 128));                                          \
+    if (hm == 32) { if (wpb == 1) hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, st, __VA_ARGS__);          \
+                    else if (wpb == 2) hipLaunchKernelGGL((KERNEL<32, 2>), grid, block, 0, st, __VA_ARGS__);     \
+                    else hipLaunchKernelGGL((KERNEL<32, 4>), grid, block, 0, st, __VA_ARGS__); }                  \
+    else if (hm == 64) { if (wpb == 1) hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, st, __VA_ARGS__);     \
+                         else if (wpb == 2) hipLaunchKernelGGL((KERNEL<64, 2>), grid, block, 0, st, __VA_ARGS__); \
+                         else hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, st, __VA_ARGS__); }             \
+    else if (hm == 96) { if (wpb == 1) hipLaunchKernelGGL((KERNEL<96, 1>), grid, block, 0, st, __VA_ARGS__);     \
+                         else if (wpb == 2) hipLaunchKernelGGL((KERNEL<96, 2>), grid, block, 0, st, __VA_ARGS__); \
+                         else hipLaunchKernelGGL((KERNEL<96, 4>), grid, block, 0, st, __VA_ARGS__); }             \
+    else { if (wpb == 1) hipLaunchKernelGGL((KERNEL<128, 1>), grid, block, 0, st, __VA_ARGS__);                   \
+           else if (wpb == 2) hipLaunchKernelGGL((KERNEL<128, 2>), grid, block, 0, st, __VA_ARGS__);              \
+           else hipLaunchKernelGGL((KERNEL<128, 4>), grid, block, 0, st, __VA_ARGS__); }                          \
+  } while (0)
+
+int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                         float* gates, hipStream_t st) {
+  if (!gru_small_supported(B, H)) return WGNN_ERR_UNSUPPORTED;
+  const double bt = (double)B * T;
+  PROF_LAUNCH("gru_small_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0)), st,
+              SMALL_DISPATCH(gru_small_fwd_kernel, B, T, H, GI, ldgi, Whh, bhh, Y, gates));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+int launch_gru_small_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
+                         float* dGI, float* dGH, int ldd, hipStream_t st) {
+  if (!gru_small_supported(B, H)) return WGNN_ERR_UNSUPPORTED;
+  const double bt = (double)B * T;
+  PROF_LAUNCH("gru_small_bwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (4 * H + 2 * H + 6 * H), st,
+              SMALL_DISPATCH(gru_small_bwd_kernel, B, T, H, Whh, Y, dY, gates, dGI, dGH, ldd));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}

@@ -97,7 +97,10 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
                                                             float* __restrict__ gates, _Float16* __restrict__ yp_hi,
                                                             _Float16* __restrict__ yp_lo, unsigned* status,
                                                             const void* __restrict__ Lab,
-                                                            float* __restrict__ stat_part, int io) {
+                                                            float* __restrict__ stat_part, int io, int last_only,
+                                                            float y_mul, float y_add) {
+  // last_only (wgnn_fwd_last, inference): Y is [B][H] fp32 and receives only h_{T-1} * y_mul + y_add -- the evaluation
+  // read-out of src/main.py:103,116 without writing (and re-reading) the other T-1 rows
   constexpr int HP = 32 * KS;                      // plane row width (halfs): h, then 1.0 at column H, then 0
   constexpr int HS = 32 * KS + 8;                  // row stride in halfs: 16-B aligned, conflict-free reads
   // h state is double-buffered: step t reads buffer t&1 and writes h_t into the other one, so a single
@@ -274,7 +277,8 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         if (IO) {
           if (jv) yt[(4 * g + r) * HY + j] = hnew[r];   // -> Y through the row copy-out below
         } else if (rowok[r]) {
-          ((float*)Yw)[(rowt[r] + t) * H + j] = hnew[r];
+          if (!last_only) ((float*)Yw)[(rowt[r] + t) * H + j] = hnew[r];
+          else if (t == T - 1) ((float*)Y)[(size_t)(b0 + 4 * g + r) * H + j] = hnew[r] * y_mul + y_add;
         }
         if (rowok[r] && Lab) {                          // the statistics use the unrounded h
           const float dl = hnew[r] - (IO ? lt[(4 * g + r) * HY + j] : lab[r]);
@@ -633,18 +637,20 @@ int grux_blocks(int B) { return cdiv_i(B, MB); }
 int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, void* Y,
                     float* gates, void* y_planes /*nullable: 2 x [B*T+1][grux_hp(H)] halfs*/, bool x3, unsigned* status,
                     const void* labels /*nullable*/, float* stat_part /*2 * grux_blocks(B) floats if labels*/, int io,
-                    hipStream_t st) {
+                    int last_only /*Y is [B][H]: only h_{T-1} * y_mul + y_add is written (fp32 I/O, no stash)*/,
+                    float y_mul, float y_add, hipStream_t st) {
+  if (last_only && (io != 0 || gates || y_planes || labels)) return WGNN_ERR_UNSUPPORTED;
   _Float16* yh = (_Float16*)y_planes;
   _Float16* yl = yh ? yh + ((size_t)B * T + 1) * grux_hp(H) : nullptr;   // each plane has B*T + 1 rows
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H,
-               by = bt * (4.0 * 3 * H + (io ? 2.0 : 4.0) * (H + (labels ? H : 0))) +
+               by = bt * (4.0 * 3 * H + (io ? 2.0 : 4.0) * ((last_only ? 0 : H) + (labels ? H : 0))) +
                     (gates ? 4.0 * grux_gates_floats(B, T, H, io) : 0.0);
   const dim3 grid(cdiv_i(B, MB));
 #define FLAUNCH(K, X3V, IOV, NAME)                                                                                 \
   PROF_LAUNCH(NAME, fl, by, st,                                                                                    \
               hipLaunchKernelGGL((grux_fwd_kernel<K, X3V, IOV>), grid, dim3(NTHREADS), 0, st, B, T, H, GI, ldgi, Whh, bhh, Y, \
-                                 gates, yh, yl, status, labels, stat_part, io))
+                                 gates, yh, yl, status, labels, stat_part, io, last_only, y_mul, y_add))
 #define FCASE(K)                                                                                                   \
   if (x3 && !io) FLAUNCH(K, true, false, "grux_fwd_kernel<" #K ">");                                               \
   else if (x3) FLAUNCH(K, true, true, "grux_fwd_kernel<" #K ">");                                                  \

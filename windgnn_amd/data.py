@@ -51,3 +51,26 @@ def predict_last(Y: torch.Tensor, wind_min: float, wind_max: float) -> torch.Ten
     _lib.check(lib.wgnn_predict_last(_ptr(Y), B, T, H, float(wind_min), float(wind_max), _ptr(out), _stream()),
                "wgnn_predict_last")
     return out
+
+
+def forward_last(model, adj_matrix, attr_matrix: torch.Tensor, wind_min: float, wind_max: float) -> torch.Tensor:
+    """The evaluation loop's `model(adj, x)` + last-row de-normalisation (src/main.py:100-103,116) as one C-ABI call,
+    wgnn_fwd_last: [B, 3S] (B = 1: [3S]) without materialising the other T-1 output rows."""
+    from .functional import _Workspace, _adj, _params_struct
+    lib = _lib.load()
+    _require_gpu(attr_matrix)
+    X = attr_matrix.contiguous()
+    B, T, S, F = X.shape
+    A, fmt, nnz = _adj(adj_matrix, S)
+    params = [p.detach() for p in model.hot_path_parameters()]
+    H = params[5].shape[1]
+    d = _lib.Dims(B, T, S, F, H, model.math, fmt, nnz, _lib.IO_F32)
+    nbytes = lib.wgnn_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        _lib.check(-5, "wgnn_workspace_bytes")
+    ws = _Workspace.get(X.device, nbytes)
+    out = torch.empty(B, H, dtype=torch.float32, device=X.device)
+    ps = _params_struct(_lib.Params, params)
+    _lib.check(lib.wgnn_fwd_last(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), float(wind_min), float(wind_max), _ptr(out),
+                                 _ptr(ws), nbytes, _stream()), "wgnn_fwd_last")
+    return out.squeeze(0)
