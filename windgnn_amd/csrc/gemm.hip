@@ -25,20 +25,50 @@ struct GemmP {
 // One thread's share (8 values) of a [BK][128] k-major LDS tile, fetched from a global operand into registers
 // (fetch) and written to LDS later (commit), so that the loads of step k+1 fly under the MFMAs of step k.
 // rows = m (or n) index, origin r0.  kcontig: element (r,k) at P[r*ld + k]; else at P[k*ld + r].
-template <bool IS_B>
-__device__ __forceinline__ void fetch(float (&v)[8], const GemmP& p, const float* P, int ld, int kcontig, int r0,
+// NV consecutive floats at src, all in bounds: 16-byte loads when src allows it, 8-byte loads next, single dwords last
+// (an odd row length, e.g. W_ih's 442, leaves every second row 8-byte aligned only)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NV>
+__device__ __forceinline__ void load_run(float (&v)[NV], const float* src) {
+  const uintptr_t a = (uintptr_t)src;
+  if ((a & 15) == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; j += 4) {
+      const f32x4 x = *(const f32x4*)(src + j);
+      v[j] = x[0]; v[j + 1] = x[1]; v[j + 2] = x[2]; v[j + 3] = x[3];
+    }
+  } else if ((a & 7) == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; j += 2) {
+      const f32x2 x = *(const f32x2*)(src + j);
+      v[j] = x[0]; v[j + 1] = x[1];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = src[j];
+  }
+}
+
+// NV values per thread: the tile has 16 NV rows (128 for NV = 8; 64 for the short-M A tile, NV = 4).
+template <bool IS_B, int NV>
+__device__ __forceinline__ void fetch(float (&v)[NV], const GemmP& p, const float* P, int ld, int kcontig, int r0,
                                       int nrows, int k0, int kend) {
   const int tid = threadIdx.x;
   if (kcontig) {
-    const int r = tid >> 1, kc = (tid & 1) * 8;
+    constexpr int TPR = BK / NV;            // threads per row
+    const int r = tid / TPR, kc = (tid % TPR) * NV;
     const int gr = r0 + r;
+    if (gr < nrows && k0 + kc + NV <= kend) {      // the whole run is in bounds: wide loads
+      load_run<NV>(v, P + (size_t)gr * ld + k0 + kc);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = k0 + kc + j;
-      v[j] = (gr < nrows && k < kend) ? P[(size_t)gr * ld + k] : 0.f;
+      for (int j = 0; j < NV; ++j) {
+        const int k = k0 + kc + j;
+        v[j] = (gr < nrows && k < kend) ? P[(size_t)gr * ld + k] : 0.f;
+      }
     }
   } else {
-    const int kk = tid >> 4, rc = (tid & 15) * 8;
+    const int kk = tid >> 4, rc = (tid & 15) * NV;
     const int k = k0 + kk;
     const bool kvalid = k < kend;
     bool krow = kvalid;                   // row carries data (the ones-column only needs kvalid)
@@ -50,43 +80,53 @@ __device__ __forceinline__ void fetch(float (&v)[8], const GemmP& p, const float
       rowoff = krow ? (size_t)k * ld : 0;
     }
     const int ndata = nrows - (IS_B ? p.ones_col : 0);
+    if (krow && r0 + rc + NV <= ndata) {           // the whole run is data of a live row: wide loads
+      load_run<NV>(v, P + rowoff + r0 + rc);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int gr = r0 + rc + j;
-      float x = 0.f;
-      if (IS_B && p.ones_col && gr == nrows - 1) x = kvalid ? 1.f : 0.f;
-      else if (krow && gr < ndata) x = P[rowoff + gr];
-      v[j] = x;
+      for (int j = 0; j < NV; ++j) {
+        const int gr = r0 + rc + j;
+        float x = 0.f;
+        if (IS_B && p.ones_col && gr == nrows - 1) x = kvalid ? 1.f : 0.f;
+        else if (krow && gr < ndata) x = P[rowoff + gr];
+        v[j] = x;
+      }
     }
   }
 }
-__device__ __forceinline__ void commit(float* T, const float (&v)[8], int kcontig) {
+template <int NV>
+__device__ __forceinline__ void commit(float* T, const float (&v)[NV], int kcontig) {
   const int tid = threadIdx.x;
   if (kcontig) {
-    const int r = tid >> 1, kc = (tid & 1) * 8;
+    constexpr int TPR = BK / NV;
+    const int r = tid / TPR, kc = (tid % TPR) * NV;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) T[(kc + j) * LDT + r] = v[j];
+    for (int j = 0; j < NV; ++j) T[(kc + j) * LDT + r] = v[j];
   } else {
-    const int kk = tid >> 4, rc = (tid & 15) * 8;
+    const int kk = tid >> 4, rc = (tid & 15) * NV;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) T[kk * LDT + rc + j] = v[j];
+    for (int j = 0; j < NV; ++j) T[kk * LDT + rc + j] = v[j];
   }
 }
 
+// MI: 32-row MFMA tiles per wave along M: 2 = the 128 x 128 tile; 1 = a 64 x 128 tile for products whose 128-row
+// tiling would leave most CUs without a workgroup (small batches: M = B*T = 6144 at BASELINE configs[1])
+template <int MI>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
+  constexpr int BMv = 64 * MI, NVA = 4 * MI;
   __shared__ __attribute__((aligned(16))) float As[BK * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = blockIdx.x * BMv, n0 = blockIdx.y * BN;
   const int z = blockIdx.z;
   const int kbeg = z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
   const int li = lane & 31, lk = lane >> 5;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -95,57 +135,68 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
   // Two-level summation: the MFMA chain over k is sequential, so every 512 k the running tile is folded into
   // `tot` (error grows with sqrt(512) + sqrt(K/512) instead of sqrt(K); K is 53 248 in the 4096-station
   // input projection).  For K <= 512 this is bitwise the single chain.
-  f32x16 tot[2][2];
+  f32x16 tot[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   int since = 0;
-  float va[8], vb[8];
-  if (kbeg < kend) {
-    fetch<false>(va, p, p.A, p.lda, p.a_kc, m0, p.M, kbeg, kend);
-    fetch<true>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg, kend);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    if (since == 512 / BK) {
+  // 64-row tile: operands of the NEXT TWO k steps are in flight in registers while the current one is multiplied (a k step of MFMAs
+  // is ~1000 cycles, less than a loaded chip's memory latency: with one step of lookahead the loads were waited for)
+  // (the 128-row tile keeps ONE stage: with two it needs 272 registers)
+  constexpr int DEPTH = MI == 1 ? 2 : 1;
+  float va[DEPTH][NVA], vb[DEPTH][8];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+  for (int u = 0; u < DEPTH; ++u)
+    if (kbeg + u * BK < kend) {
+      fetch<false, NVA>(va[u], p, p.A, p.lda, p.a_kc, m0, p.M, kbeg + u * BK, kend);
+      fetch<true, 8>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg + u * BK, kend);
+    }
+  for (int kq = kbeg; kq < kend; kq += DEPTH * BK) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          tot[i][j] += acc[i][j];
+    for (int u = 0; u < DEPTH; ++u) {
+      const int k0 = kq + u * BK;
+      if (k0 >= kend) break;            // workgroup-uniform
+      if (since == 512 / BK) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            tot[i][j] += acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+        since = 0;
+      }
+      ++since;
+      commit<NVA>(As, va[u], p.a_kc);
+      commit<8>(Bs, vb[u], p.b_kc);
+      __syncthreads();
+      if (k0 + DEPTH * BK < kend) {     // refill this register stage
+        fetch<false, NVA>(va[u], p, p.A, p.lda, p.a_kc, m0, p.M, k0 + DEPTH * BK, kend);
+        fetch<true, 8>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + DEPTH * BK, kend);
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float b0 = Bs[(kk + lk) * LDT + wn + li];
+        const float b1 = Bs[(kk + lk) * LDT + wn + 32 + li];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const float a = As[(kk + lk) * LDT + wm + 32 * i + li];
+          acc[i][0] = mfma32(a, b0, acc[i][0]);
+          acc[i][1] = mfma32(a, b1, acc[i][1]);
         }
-      since = 0;
+      }
+      __syncthreads();
     }
-    ++since;
-    commit(As, va, p.a_kc);
-    commit(Bs, vb, p.b_kc);
-    __syncthreads();
-    if (k0 + BK < kend) {               // next step's operands: in flight under this step's MFMAs
-      fetch<false>(va, p, p.A, p.lda, p.a_kc, m0, p.M, k0 + BK, kend);
-      fetch<true>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + BK, kend);
-    }
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a0 = As[(kk + lk) * LDT + wm + li];
-      float a1 = As[(kk + lk) * LDT + wm + 32 + li];
-      float b0 = Bs[(kk + lk) * LDT + wn + li];
-      float b1 = Bs[(kk + lk) * LDT + wn + 32 + li];
-      acc[0][0] = mfma32(a0, b0, acc[0][0]);
-      acc[0][1] = mfma32(a0, b1, acc[0][1]);
-      acc[1][0] = mfma32(a1, b0, acc[1][0]);
-      acc[1][1] = mfma32(a1, b1, acc[1][1]);
-    }
-    __syncthreads();
   }
 
   float* C = p.partial ? p.partial + (size_t)z * p.M * p.N : p.C;
   const int ldc = p.partial ? p.N : p.ldc;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn + 32 * j + li;
@@ -196,10 +247,16 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
   p.splitk = g.splitk < 1 ? 1 : g.splitk;
   p.kchunk = cdiv_i(cdiv_i(g.K, p.splitk), BK) * BK;
   p.partial = g.partial;
-  dim3 grid(cdiv_i(g.M, BM), cdiv_i(g.N, BN), p.splitk);
   const double fl = 2.0 * g.M * (double)g.N * g.K;
   const double by = 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N * p.splitk);
-  PROF_LAUNCH("gemm_f32_kernel", fl, by, st, hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, p));
+  // 64-row tiles when the 128-row tiling would not give every CU a workgroup
+  if (cdiv_i(g.M, BM) * cdiv_i(g.N, BN) * p.splitk < 256) {
+    dim3 grid(cdiv_i(g.M, 64), cdiv_i(g.N, BN), p.splitk);
+    PROF_LAUNCH("gemm_f32_kernel<64>", fl, by, st, hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, p));
+  } else {
+    dim3 grid(cdiv_i(g.M, BM), cdiv_i(g.N, BN), p.splitk);
+    PROF_LAUNCH("gemm_f32_kernel", fl, by, st, hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, st, p));
+  }
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

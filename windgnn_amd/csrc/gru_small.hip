@@ -5,10 +5,10 @@
 //
 // gru.hip gives a workgroup 16 windows (one MFMA M tile): at BASELINE configs[1] (B = 256) that is 16 workgroups on
 // 256 CUs, and the launch lasts as long as ONE workgroup's 24 dependent steps (126 / 163 us forward / backward).
-// Here a workgroup owns WPB <= 4 windows, thread i owns gate row i of W_hh (forward: the row itself, 4H bytes of
+// Here a workgroup owns ONE window (the WPB template parameter stays 1: more windows per workgroup spill), thread i owns gate row i of W_hh (forward: the row itself, 4H bytes of
 // registers; backward: column j of gate block q, i = q H + j) and the per-step matrix-vector products are plain fp32
 // FMA chains against h / dgh broadcast from LDS: no MFMA tile to fill, ~B workgroups instead of B/16, and a step costs
-// ~H FMAs per thread.  Used when B <= 2048; results are fp32 fmaf chains like gru.hip's (different summation order).
+// ~H FMAs per thread.  Used when B <= 1024; results are fp32 fmaf chains like gru.hip's (different summation order).
 #include "common.h"
 
 namespace {
@@ -21,7 +21,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
                                                                       const float* __restrict__ GI, int ldgi,
                                                                       const float* __restrict__ Whh,
                                                                       const float* __restrict__ bhh,
-                                                                      float* __restrict__ Y, float* __restrict__ gates) {
+                                                                      float* __restrict__ Y, float* __restrict__ gates,
+                                                                      int stage_w) {
   __shared__ __attribute__((aligned(16))) float hs[WPB][HMAX];       // h_{t-1}, zero beyond H
   __shared__ float ghs[WPB][3 * HMAX];                               // W_hh h + b_hh, gate-major with stride HMAX
   const int i = threadIdx.x;
@@ -29,9 +30,21 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
   const bool iv = i < G3;
   const int ic = iv ? i : G3 - 1;
   const int q = ic / H, jq = ic % H;                                  // gate and unit of this thread's row
+  // This thread's row of W_hh into registers.  Read straight from HBM / L2 each lane of a load would touch its own
+  // cache line (rows are H floats apart): 112 loads x 64 lines per wave, ~33 us per workgroup.  So W_hh comes in
+  // linearly (coalesced) through LDS when it fits (3 H^2 floats of dynamic LDS: H <= 108) and each thread picks its
+  // row out of the staged copy; larger H takes the strided loads.
   float w[HMAX];
+  extern __shared__ __attribute__((aligned(16))) float wst[];
+  if (stage_w) {
+    for (int e = threadIdx.x; e < G3 * H; e += blockDim.x) wst[e] = Whh[e];
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < HMAX; ++k) w[k] = k < H ? Whh[(size_t)ic * H + k] : 0.f;
+    for (int k = 0; k < HMAX; ++k) w[k] = k < H ? wst[ic * H + k] : 0.f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < HMAX; ++k) w[k] = k < H ? Whh[(size_t)ic * H + k] : 0.f;
+  }
   const float bh = bhh[ic];
   const int b0 = blockIdx.x * WPB;
   for (int k = threadIdx.x; k < WPB * HMAX; k += blockDim.x) (&hs[0][0])[k] = 0.f;
@@ -58,17 +71,19 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
     load_gi(t + 1, gin);                            // next step's input projection, in flight under this step
     float acc[WPB];
 #pragma unroll
-    for (int wdw = 0; wdw < WPB; ++wdw) acc[wdw] = bh;
+    for (int wdw = 0; wdw < WPB; ++wdw) {
+      // four independent partial sums (k = 0,1,2,3 mod 4): the FMA chain is 4x shorter than H; fixed order => deterministic
+      float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int k4 = 0; k4 < HMAX / 4; ++k4) {
-#pragma unroll
-      for (int wdw = 0; wdw < WPB; ++wdw) {
+      for (int k4 = 0; k4 < HMAX / 4; ++k4) {
         const f32x4 hv = *(const f32x4*)&hs[wdw][4 * k4];          // same address in every lane: LDS broadcast
-        acc[wdw] = fmaf(w[4 * k4 + 0], hv[0], acc[wdw]);
-        acc[wdw] = fmaf(w[4 * k4 + 1], hv[1], acc[wdw]);
-        acc[wdw] = fmaf(w[4 * k4 + 2], hv[2], acc[wdw]);
-        acc[wdw] = fmaf(w[4 * k4 + 3], hv[3], acc[wdw]);
+        a0 = fmaf(w[4 * k4 + 0], hv[0], a0);
+        a1 = fmaf(w[4 * k4 + 1], hv[1], a1);
+        a2 = fmaf(w[4 * k4 + 2], hv[2], a2);
+        a3 = fmaf(w[4 * k4 + 3], hv[3], a3);
+
       }
+      acc[wdw] = (a0 + a1) + (a2 + a3);
     }
     if (iv) {
 #pragma unroll
@@ -80,9 +95,9 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
       for (int wdw = 0; wdw < WPB; ++wdw) {
         const int b = b0 + wdw;
         const float ghn = ghs[wdw][2 * HMAX + j];
-        const float rg = sigmoidf_(gi[wdw][0] + ghs[wdw][j]);
-        const float zg = sigmoidf_(gi[wdw][1] + ghs[wdw][HMAX + j]);
-        const float ng = tanhf_(gi[wdw][2] + rg * ghn);
+        const float rg = sigmoid_fast(gi[wdw][0] + ghs[wdw][j]);      // v_exp / v_rcp forms, |error| < 3e-7 (common.h)
+        const float zg = sigmoid_fast(gi[wdw][1] + ghs[wdw][HMAX + j]);
+        const float ng = tanh_fast(gi[wdw][2] + rg * ghn);
         const float hnew = (1.f - zg) * ng + zg * hs[wdw][j];
         hs[wdw][j] = hnew;
         if (b < B) {
@@ -200,17 +215,18 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
     if (t > 0) {
       float p[WPB];
 #pragma unroll
-      for (int wdw = 0; wdw < WPB; ++wdw) p[wdw] = 0.f;
+      for (int wdw = 0; wdw < WPB; ++wdw) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-      for (int k4 = 0; k4 < HMAX / 4; ++k4) {
-#pragma unroll
-        for (int wdw = 0; wdw < WPB; ++wdw) {
+        for (int k4 = 0; k4 < HMAX / 4; ++k4) {
           const f32x4 dv = *(const f32x4*)&dghs[wdw][q * HMAX + 4 * k4];
-          p[wdw] = fmaf(dv[0], wT[4 * k4 + 0], p[wdw]);
-          p[wdw] = fmaf(dv[1], wT[4 * k4 + 1], p[wdw]);
-          p[wdw] = fmaf(dv[2], wT[4 * k4 + 2], p[wdw]);
-          p[wdw] = fmaf(dv[3], wT[4 * k4 + 3], p[wdw]);
+          a0 = fmaf(dv[0], wT[4 * k4 + 0], a0);
+          a1 = fmaf(dv[1], wT[4 * k4 + 1], a1);
+          a2 = fmaf(dv[2], wT[4 * k4 + 2], a2);
+          a3 = fmaf(dv[3], wT[4 * k4 + 3], a3);
+
         }
+        p[wdw] = (a0 + a1) + (a2 + a3);
       }
       if (iv) {
 #pragma unroll
@@ -228,37 +244,48 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
   }
 }
 
-int pick_wpb(int B) { return B <= 512 ? 1 : (B <= 1024 ? 2 : 4); }
+int pick_wpb(int B) { return 1; }   // 2 and 4 windows per workgroup spill at H > 96 (604-848 B of scratch): 409 us at B = 1024
 
 }  // namespace
 
-bool gru_small_supported(int B, int H) { return H >= 1 && H <= 128 && B <= 2048; }
+// B workgroups of ~25 us each: up to 1024 windows that beats gru.hip's B/16 workgroups of 126 / 163 us
+bool gru_small_supported(int B, int H) { return H >= 1 && H <= 128 && B <= 1024; }
 
 #define SMALL_DISPATCH(KERNEL, ...)                                                                              \
   do {                                                                                                           \
-    const int wpb = pick_wpb(B);                                                                                 \
-    const dim3 grid(cdiv_i(B, wpb)), block(cdiv_i(3 * H, 64) * 64);                                              \
-    const int hm = H <= 32 ? 32 : (H <= 64 ? 64 : (H <= 96 ? 96 : 128));                                          \
-    if (hm == 32) { if (wpb == 1) hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, st, __VA_ARGS__);          \
-                    else if (wpb == 2) hipLaunchKernelGGL((KERNEL<32, 2>), grid, block, 0, st, __VA_ARGS__);     \
-                    else hipLaunchKernelGGL((KERNEL<32, 4>), grid, block, 0, st, __VA_ARGS__); }                  \
-    else if (hm == 64) { if (wpb == 1) hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, st, __VA_ARGS__);     \
-                         else if (wpb == 2) hipLaunchKernelGGL((KERNEL<64, 2>), grid, block, 0, st, __VA_ARGS__); \
-                         else hipLaunchKernelGGL((KERNEL<64, 4>), grid, block, 0, st, __VA_ARGS__); }             \
-    else if (hm == 96) { if (wpb == 1) hipLaunchKernelGGL((KERNEL<96, 1>), grid, block, 0, st, __VA_ARGS__);     \
-                         else if (wpb == 2) hipLaunchKernelGGL((KERNEL<96, 2>), grid, block, 0, st, __VA_ARGS__); \
-                         else hipLaunchKernelGGL((KERNEL<96, 4>), grid, block, 0, st, __VA_ARGS__); }             \
-    else { if (wpb == 1) hipLaunchKernelGGL((KERNEL<128, 1>), grid, block, 0, st, __VA_ARGS__);                   \
-           else if (wpb == 2) hipLaunchKernelGGL((KERNEL<128, 2>), grid, block, 0, st, __VA_ARGS__);              \
-           else hipLaunchKernelGGL((KERNEL<128, 4>), grid, block, 0, st, __VA_ARGS__); }                          \
+    const dim3 grid(B), block(cdiv_i(3 * H, 64) * 64);                                                           \
+    if (H <= 32) hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, st, __VA_ARGS__);                           \
+    else if (H <= 64) hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, st, __VA_ARGS__);                      \
+    else if (H <= 96) hipLaunchKernelGGL((KERNEL<96, 1>), grid, block, 0, st, __VA_ARGS__);                      \
+    else if (H <= 112) hipLaunchKernelGGL((KERNEL<112, 1>), grid, block, 0, st, __VA_ARGS__);                    \
+    else hipLaunchKernelGGL((KERNEL<128, 1>), grid, block, 0, st, __VA_ARGS__);                                  \
   } while (0)
+
+template <int HMAX>
+static int launch_small_fwd_t(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                              float* gates, hipStream_t st) {
+  const size_t wbytes = (size_t)3 * H * H * sizeof(float);
+  const int stage_w = wbytes <= 140 * 1024;
+  const size_t smem = stage_w ? wbytes : 0;
+  static std::atomic<unsigned long long> done{0};
+  if (ensure_dyn_smem((const void*)gru_small_fwd_kernel<HMAX, 1>, 140 * 1024, done) != WGNN_OK) return WGNN_ERR_HIP;
+  hipLaunchKernelGGL((gru_small_fwd_kernel<HMAX, 1>), dim3(B), dim3(cdiv_i(3 * H, 64) * 64), smem, st, B, T, H, GI, ldgi,
+                     Whh, bhh, Y, gates, stage_w);
+  return WGNN_OK;
+}
 
 int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
                          float* gates, hipStream_t st) {
   if (!gru_small_supported(B, H)) return WGNN_ERR_UNSUPPORTED;
   const double bt = (double)B * T;
+  int rc = WGNN_OK;
   PROF_LAUNCH("gru_small_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0)), st,
-              SMALL_DISPATCH(gru_small_fwd_kernel, B, T, H, GI, ldgi, Whh, bhh, Y, gates));
+              rc = H <= 32   ? launch_small_fwd_t<32>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st)
+                   : H <= 64 ? launch_small_fwd_t<64>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st)
+                   : H <= 96 ? launch_small_fwd_t<96>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st)
+                   : H <= 112 ? launch_small_fwd_t<112>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st)
+                              : launch_small_fwd_t<128>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st));
+  if (rc != WGNN_OK) return rc;
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
