@@ -157,3 +157,17 @@ def test_reference_import_header_resolves_with_the_documented_swap():
     m = ns["GCN_GRU"](input_dim=13, hidden_dim=13, output_dim=13, gru_input=7 * 13, gru_hidden_dim=21)
     assert list(m.state_dict().keys()) == PARAM_KEYS
     assert callable(ns["torch"].optim.Adam)                           # src/main.py:52
+
+
+def test_host_asan_build_of_the_c_abi_is_clean():
+    """the C-ABI library's host code (layouts, validation, launch wrappers) under AddressSanitizer
+    (`hipcc -fsanitize=address -fno-gpu-sanitize`, CPU box only): 4032 shapes through every size function and every
+    entry point's argument validation, no ASan report (tools/asan_host_check.py)."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_host_check.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "no report" in r.stdout
