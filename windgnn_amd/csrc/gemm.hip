@@ -114,8 +114,10 @@ __device__ __forceinline__ void commit(float* T, const float (&v)[NV], int kcont
 template <int MI>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
   constexpr int BMv = 64 * MI, NVA = 4 * MI;
-  __shared__ __attribute__((aligned(16))) float As[BK * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+  // two LDS stages: step k is multiplied out of stage k & 1 while step k+1's operands (loaded into registers during
+  // step k-1) are committed to the other stage and step k+2's loads are issued -- ONE barrier per k step
+  __shared__ __attribute__((aligned(16))) float As2[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs2[2][BK * LDT];
   const int m0 = blockIdx.x * BMv, n0 = blockIdx.y * BN;
   const int z = blockIdx.z;
   const int kbeg = z * p.kchunk;
@@ -143,54 +145,54 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   int since = 0;
-  // 64-row tile: operands of the NEXT TWO k steps are in flight in registers while the current one is multiplied (a k step of MFMAs
-  // is ~1000 cycles, less than a loaded chip's memory latency: with one step of lookahead the loads were waited for)
-  // (the 128-row tile keeps ONE stage: with two it needs 272 registers)
-  constexpr int DEPTH = MI == 1 ? 2 : 1;
-  float va[DEPTH][NVA], vb[DEPTH][8];
-#pragma unroll
-  for (int u = 0; u < DEPTH; ++u)
-    if (kbeg + u * BK < kend) {
-      fetch<false, NVA>(va[u], p, p.A, p.lda, p.a_kc, m0, p.M, kbeg + u * BK, kend);
-      fetch<true, 8>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg + u * BK, kend);
+  float va[NVA], vb[8];
+  if (kbeg < kend) {
+    fetch<false, NVA>(va, p, p.A, p.lda, p.a_kc, m0, p.M, kbeg, kend);
+    fetch<true, 8>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg, kend);
+    commit<NVA>(As2[0], va, p.a_kc);
+    commit<8>(Bs2[0], vb, p.b_kc);
+    if (kbeg + BK < kend) {
+      fetch<false, NVA>(va, p, p.A, p.lda, p.a_kc, m0, p.M, kbeg + BK, kend);
+      fetch<true, 8>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg + BK, kend);
     }
-  for (int kq = kbeg; kq < kend; kq += DEPTH * BK) {
+  }
+  __syncthreads();
+  int stg = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK, stg ^= 1) {
+    if (since == 512 / BK) {
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
-      const int k0 = kq + u * BK;
-      if (k0 >= kend) break;            // workgroup-uniform
-      if (since == 512 / BK) {
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < 2; ++j) {
+          tot[i][j] += acc[i][j];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            tot[i][j] += acc[i][j];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-          }
-        since = 0;
-      }
-      ++since;
-      commit<NVA>(As, va[u], p.a_kc);
-      commit<8>(Bs, vb[u], p.b_kc);
-      __syncthreads();
-      if (k0 + DEPTH * BK < kend) {     // refill this register stage
-        fetch<false, NVA>(va[u], p, p.A, p.lda, p.a_kc, m0, p.M, k0 + DEPTH * BK, kend);
-        fetch<true, 8>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + DEPTH * BK, kend);
-      }
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        const float b0 = Bs[(kk + lk) * LDT + wn + li];
-        const float b1 = Bs[(kk + lk) * LDT + wn + 32 + li];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const float a = As[(kk + lk) * LDT + wm + 32 * i + li];
-          acc[i][0] = mfma32(a, b0, acc[i][0]);
-          acc[i][1] = mfma32(a, b1, acc[i][1]);
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
-      }
-      __syncthreads();
+      since = 0;
     }
+    ++since;
+    if (k0 + BK < kend) {               // step k+1: registers (loaded during step k-1) -> the other LDS stage
+      commit<NVA>(As2[stg ^ 1], va, p.a_kc);
+      commit<8>(Bs2[stg ^ 1], vb, p.b_kc);
+    }
+    if (k0 + 2 * BK < kend) {           // step k+2: in flight under this step's MFMAs
+      fetch<false, NVA>(va, p, p.A, p.lda, p.a_kc, m0, p.M, k0 + 2 * BK, kend);
+      fetch<true, 8>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + 2 * BK, kend);
+    }
+    const float* As = As2[stg];
+    const float* Bs = Bs2[stg];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float b0 = Bs[(kk + lk) * LDT + wn + li];
+      const float b1 = Bs[(kk + lk) * LDT + wn + 32 + li];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const float a = As[(kk + lk) * LDT + wm + 32 * i + li];
+        acc[i][0] = mfma32(a, b0, acc[i][0]);
+        acc[i][1] = mfma32(a, b1, acc[i][1]);
+      }
+    }
+    __syncthreads();                    // stage stg is free for step k+2; stage stg^1 is complete
   }
 
   float* C = p.partial ? p.partial + (size_t)z * p.M * p.N : p.C;
