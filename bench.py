@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 PMC passes (N = 1 only)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-fp32 secondary measurement")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the collective step even with one rank (rehearses the "
+                         "N > 1 code path on a one-GPU box; launch with torch.distributed.run --nproc-per-node 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -209,7 +212,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     from windgnn_amd import GCN_GRU, _lib
@@ -219,13 +223,13 @@ def main():
     S, H = (34, 102) if args.workload == "c3" else (4096, 12288)
     B = args.batch or (4096 if args.workload == "c3" else 128)
     model = GCN_GRU(F, F, F, S * F, H, math=args.math).to(dev)
-    trainer = TrainStep(model)
+    trainer = TrainStep(model, process_group=dist.group.WORLD if use_dist else None)
     A = (adjacency_34() if args.workload == "c3" else adjacency_knn(S)).to(dev)
     X, L = make_inputs(B, rank, dev, S, H, args.io)
     esz = 4.0 if args.io == "fp32" else 2.0
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -240,7 +244,7 @@ def main():
     if args.traffic_child:
         return
     trainer.check()                                     # fp16-plane modes: nothing left fp16's range
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -361,7 +365,9 @@ def main():
             "config": {"workload": "S=%d stations%s, T=24, F=13, H=%d, B=%d windows/GPU; step = forward + MSE + "
                                    "backward + grad all-reduce (N>1) + Adam; %s I/O"
                                    % (S, "" if args.workload == "c3" else " (symmetric 8-NN graph, CSR)", H, B, args.io),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "math": args.math},
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "math": args.math,
+                       "collective": ("rccl all-reduce x2 per step (GRU grads overlapped with backward part 2; conv grads + loss)"
+                                      if use_dist else "none (one rank)")},
             "loss": round(float(loss), 6),
             "roofline": roofline,
             "path": path,
@@ -373,7 +379,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

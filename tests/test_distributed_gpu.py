@@ -89,3 +89,26 @@ def test_rccl_allreduce_path_executes_and_is_bitwise_neutral_with_one_rank(tmp_p
     assert np.array_equal(p0, p1)
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "loss_plain.npy")),
                           np.load(os.path.join(str(tmp_path), "loss_rccl1.npy")))
+
+
+def test_bench_multi_gpu_code_path_runs_under_torchrun_with_rccl():
+    """bench.py's N > 1 path -- RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, init_process_group("nccl"),
+    barriers, the collective TrainStep, max-over-ranks timing, destroy -- rehearsed with ONE rank on the one GPU of this
+    box (`--force-dist`); the JSON line must carry the contract's keys and a sane value."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5",
+           "--warmup", "2", "--force-dist", "--no-cpu-baseline", "--no-traffic", "--no-secondary", "--batch", "512"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 5 and out["value"] > 1e4 and out["scaling"] == "weak"
+    assert "rccl" in out["config"]["collective"]

@@ -37,7 +37,12 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
   float w[HMAX];
   extern __shared__ __attribute__((aligned(16))) float wst[];
   if (stage_w) {
-    for (int e = threadIdx.x; e < G3 * H; e += blockDim.x) wst[e] = Whh[e];
+    const int nw = G3 * H;
+    if ((nw & 3) == 0 && (((uintptr_t)Whh) & 15) == 0) {    // 16-byte copies, several in flight per thread
+      for (int e = threadIdx.x; e < nw / 4; e += blockDim.x) ((f32x4*)wst)[e] = ((const f32x4*)Whh)[e];
+    } else {
+      for (int e = threadIdx.x; e < nw; e += blockDim.x) wst[e] = Whh[e];
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < HMAX; ++k) w[k] = k < H ? wst[ic * H + k] : 0.f;
