@@ -66,9 +66,11 @@ def test_inference_no_grad_matches(golden):
 
 @pytest.mark.parametrize("math", ["f32", "f16x3"])
 @pytest.mark.parametrize("S,T,B,H", [(34, 24, 256, 102), (7, 12, 32, 21), (34, 24, 37, 102), (5, 3, 17, 9),
-                                     (16, 4, 16, 48), (48, 2, 3, 33), (1, 1, 1, 1)])
+                                     (16, 4, 16, 48), (48, 2, 3, 33), (1, 1, 1, 1),
+                                     (64, 3, 2, 127), (33, 1, 19, 100), (2, 7, 33, 6), (34, 24, 1100, 102)])
 def test_against_oracle_random(S, T, B, H, math):
-    """BASELINE configs[1] (S=34,T=24,B=256 fp32), configs[0] shape, and ragged / edge shapes."""
+    """BASELINE configs[1] (S=34,T=24,B=256 fp32), configs[0] shape, ragged / edge shapes, the limits of the fast
+    kernels (S = 64 stations, H = 127), a single timestep, and a batch just past the small-batch kernels' range."""
     from oracle import windgnn_oracle as orc
     dev = _dev()
     g = torch.Generator().manual_seed(1000 + S * 7 + B)

@@ -86,8 +86,9 @@ Layout make_layout(const wgnn_dims* d) {
     L.sk_ih = pick_splitk(L.BT, pgemm_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64);   // one workgroup per CU
     L.sk_hh = pick_splitk(L.BT, pgemm_tn_tiles(L.m_hh, (int)L.H + 1), 256, 64);
   } else {
-    L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128), 1024, 256);
-    L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128), 1024, 256);
+    // K chunks of at least 128 rows (B*T = 6144 at BASELINE configs[1]: with 256-row chunks the dW_hh product had 72 workgroups)
+    L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128), 1024, 128);
+    L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128), 1024, 128);
   }
   size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
   size_t part_hh = (size_t)L.sk_hh * L.G3 * (L.H + 1);
@@ -101,7 +102,7 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_dg = o; o += al(L.BT * L.I);
   L.ws_part = o; o += al(part_ih > part_hh ? part_ih : part_hh);
   {
-    size_t a = gcn2_bwd_partial_floats((int)L.BT), b = gcnx2_bwd_partial_floats((int)L.BT);
+    size_t a = gcn32_bwd_partial_floats((int)L.BT), b = gcnx2_bwd_partial_floats((int)L.BT);
     if (L.gen_gcn) a = gcn_csr_bwd_partial_floats();
     L.ws_gcnpart = o; o += al(a > b ? a : b);
   }
@@ -240,7 +241,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
     rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, (const float*)X, p->conv1_weight, p->conv1_bias,
                              p->conv2_weight, p->conv2_bias, h1, g, nullptr, L.Ip, false, nullptr, st);
   } else {
-    rc = launch_gcn2_fwd((int)L.BT, d->S, A, (const float*)X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
+    rc = launch_gcn32_fwd((int)L.BT, d->S, A, (const float*)X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
                          (int)L.Ip, st);
   }
   if (rc != WGNN_OK) return rc;
@@ -451,7 +452,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, gact, nullptr, L.Ip, dg,
                                L.I, nullptr, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
                                g->conv2_weight, g->conv2_bias, st);
-  return launch_gcn2_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
+  return launch_gcn32_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                          g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);
 }
 }  // namespace

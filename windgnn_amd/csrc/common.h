@@ -131,6 +131,13 @@ int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const flo
                     float* db1, float* dW2, float* db2, float* partial, hipStream_t st);
 int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
                               unsigned* status, hipStream_t st);
+// register-chained exact-fp32 variants (gcn32.hip): what the WGNN_MATH_F32 path runs
+size_t gcn32_bwd_partial_floats(int ntiles);
+int launch_gcn32_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+                     const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
+int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+                     const float* W2, const float* g, int ldg, const float* dg, float* dW1, float* db1, float* dW2,
+                     float* db2, float* partial, hipStream_t st);
 // register-chained split-fp16 variants (gcnx.hip)
 size_t gcnx2_bwd_partial_floats(int ntiles);
 int gcnx_bwd_grid(int ntiles, int S);

@@ -1,0 +1,432 @@
+// Two-layer graph convolution in EXACT fp32, register-chained on v_mfma_f32_16x16x4_f32.
+//
+// Reference: the two GraphConvLayer calls of GCN_GRU.forward (src/step6_gcn_gru_combined_model.py:17-20; layer =
+// src/step5_gcn_layer_model.py:13-23, relu((A X) W + b)) and their autograd backward (src/main.py:79).
+//
+// Same structure as gcnx.hip (one wavefront owns one (window, timestep) tile end to end; products chained through the
+// accumulator registers), but on the fp32-input MFMA: every product is bitwise an fp32 fmaf chain and nothing is split
+// or converted.  For v_mfma_f32_16x16x4_f32 the A operand is ONE float per lane (lane l: A[m = l&15][k = l>>4]), the B
+// operand one float (B[k = l>>4][n = l&15]) and C/D is lane = column, 4 registers = rows 4(l>>4) + r.  So register r of
+// an accumulator tile T IS an operand of one 16x16x4 product that contracts over T's row index:
+//     as B operand:  sum_g  M[m][row 4g+r] * T[row 4g+r][col]      (M's fragment pre-permuted: k slot g <-> row 4g+r)
+//     as A operand:  sum_g  T[row 4g+r][m] * N[row 4g+r][col]      (= T^T N)
+// A 48-station product is 3 x 3 x 4 = 36 such MFMAs, a 13 -> 16 feature product 4 per row tile.  gcn.hip's LDS-operand
+// kernels (kept for the single-layer GraphConvLayer API, which also returns dX) spent 416 / 761 us per call at
+// B = 4096 on exactly this work; the chained forms need 96 / 156 MFMAs per tile and almost no VALU.
+//
+// Forward chain:  U1[s'][f'] = X W1;  H1t[f][s] = relu(U1^T A^T + b1);  U2[s][f'] = H1 W2;  g^T[f'][s] = relu(U2^T A^T + b2)
+// Backward chain: see gcn32_bwd_kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int F13 = 13;
+constexpr int FP = 16;
+constexpr int PART = 2 * FP * FP + 2 * FP;   // dW1 | dW2 | db1 | db2, the partial layout of gcn.hip / gcnx.hip
+constexpr int XS = 20;                       // row stride (floats) of the per-wave [station][.] LDS tiles
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Linear tile element pairs (2p, 2p+1), p = lane + 64k, <-> LDS offsets s*XS + f (as in gcnx.hip): elements past the
+// tile map to a dump slot no fragment read touches, so every LDS access is unconditional.
+template <int NP>
+struct PairMap {
+  int o0[NP], o1[NP];
+  __device__ __forceinline__ void init(int lane, int I, int dump) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int e = 2 * (lane + 64 * k);
+      o0[k] = e < I ? (e / F13) * XS + (e % F13) : dump;
+      o1[k] = e + 1 < I ? ((e + 1) / F13) * XS + ((e + 1) % F13) : dump;
+    }
+  }
+};
+template <int NP>
+__device__ __forceinline__ void gload_pairs(f32x2 (&r)[NP], const float* __restrict__ src, int lane, int I) {
+  const int npairs = (I + 1) / 2;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (64 * k < npairs) {                               // wave-uniform
+      const int p = lane + 64 * k;
+      r[k] = *(const f32x2*)(src + 2 * (p < npairs ? p : npairs - 1));
+    }
+  }
+}
+
+// A[m][k] with m = 16 mi + c and k = 16 i + 4 g + r (TRANSPOSE: A[k][m]); zero outside S x S
+__device__ __forceinline__ float a_elem(const float* __restrict__ A, int S, int m, int k, bool transpose) {
+  if (m >= S || k >= S) return 0.f;
+  return transpose ? A[k * S + m] : A[m * S + k];
+}
+
+constexpr int FWD_WAVES = 8;
+
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64 * FWD_WAVES) gcn32_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
+                                                                  const float* __restrict__ X,
+                                                                  const float* __restrict__ W1,
+                                                                  const float* __restrict__ b1,
+                                                                  const float* __restrict__ W2,
+                                                                  const float* __restrict__ b2, float* __restrict__ gout,
+                                                                  int ldg) {
+  constexpr int SP = 16 * NT;
+  constexpr int NP = (SP * F13 / 2 + 63) / 64;
+  __shared__ __attribute__((aligned(16))) float sbuf[FWD_WAVES * 2 * SP * XS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int I = S * F13;
+  float* xb = sbuf + wave * 2 * SP * XS;
+  float* ob = xb + SP * XS;
+  for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;   // pads (f >= 13, s >= S) stay zero forever
+
+  // constant fragments, in registers for the whole launch
+  float CT[NT][NT][4];      // B operand of "x A^T": A[s = 16 n + c][s' = 16 i + 4 g + r]
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) CT[n][i][r] = a_elem(A, S, 16 * n + c, 16 * i + 4 * g + r, false);
+  float FW1[4], FW2[4], bb1[4], bb2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * g + r;                                  // k slot g of "step" r <-> feature 4 g + r
+    FW1[r] = (f < F13 && c < F13) ? W1[f * F13 + c] : 0.f;
+    FW2[r] = (f < F13 && c < F13) ? W2[f * F13 + c] : 0.f;
+    bb1[r] = f < F13 ? b1[f] : 0.f;
+    bb2[r] = f < F13 ? b2[f] : 0.f;
+  }
+  PairMap<NP> map;
+  map.init(lane, I, SP * XS - 1);
+  const int npairs = (I + 1) / 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+
+  f32x2 xr[NP];
+  auto stage_x = [&]() {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (64 * k < npairs) {
+        xb[map.o0[k]] = xr[k][0];
+        xb[map.o1[k]] = xr[k][1];
+      }
+    }
+  };
+  if (wave_id < ntiles) {
+    gload_pairs<NP>(xr, X + (size_t)wave_id * I, lane, I);
+    stage_x();
+  }
+  for (int tile = wave_id; tile < ntiles; tile += nwaves) {
+    wave_lds_fence();                                          // this tile's X is staged
+    const bool more = tile + nwaves < ntiles;
+    if (more) gload_pairs<NP>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch the next tile
+
+    f32x4 U[NT];                                               // U1 row tile i: [s = 16 i + 4 g + r][f' = c]
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const f32x4 xv = *(const f32x4*)(xb + (16 * i + c) * XS + 4 * g);      // X[s = 16 i + c][f = 4 g + 0..3]
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma16(xv[r], FW1[r], acc);
+      U[i] = acc;
+    }
+    f32x4 Ht[NT];                                              // H1^T column tile n: [f = 4 g + r][s = 16 n + c]
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(U[i][r], CT[n][i][r], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ht[n][r] = fmaxf(acc[r] + bb1[r], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {                             // U2 row tile i: [s = 16 i + 4 g + r][f' = c]
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma16(Ht[i][r], FW2[r], acc);
+      U[i] = acc;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(U[i][r], CT[n][i][r], acc);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bb2[r], 0.f);
+      *(f32x4*)(ob + (16 * n + c) * XS + 4 * g) = v;           // g^T[f' = 4 g + r][s] -> staged [s][f']
+    }
+    wave_lds_fence();
+    if (more) stage_x();                                       // next tile's X (xb was last read by the U1 products)
+    {                                                          // coalesced copy-out of g[tile][0 .. I)
+      float* dst = gout + (size_t)tile * ldg;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (64 * k < npairs) {
+          const int p = lane + 64 * k, e = 2 * p;
+          const f32x2 v = {ob[map.o0[k]], ob[map.o1[k]]};
+          if (e + 1 < I) *(f32x2*)(dst + e) = v;
+          else if (e < I) dst[e] = v[0];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of both layers for one tile (no dX: the input does not require grad).  With
+//   U1 = X W1, H1 = relu(A U1 + b1)      (recomputed),  dZ2 = dg * (g > 0)
+//   dU2 = A^T dZ2                 dW2 += H1^T dU2        db2 += colsum(dZ2)
+//                                 dH1 = dU2 W2^T         dZ1 = dH1 * (H1 > 0)
+//   dU1 = A^T dZ1                 dW1 += X^T dU1         db1 += colsum(dZ1)
+// every stack is kept [station rows][feature column = lane]; the one contraction over a column index (dU2 W2^T) goes
+// through the wave's LDS tile.  A and A^T fragments are shared by the block's waves through LDS.
+constexpr int BWD_WAVES = 12;   // 143 VGPRs = 3 waves per SIMD: one 12-wave block per CU (8-wave blocks left it at 2 per SIMD: 444 us)
+
+template <int NT>
+__global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
+                                                                  const float* __restrict__ X,
+                                                                  const float* __restrict__ W1,
+                                                                  const float* __restrict__ b1,
+                                                                  const float* __restrict__ W2,
+                                                                  const float* __restrict__ gact, int ld_g,
+                                                                  const float* __restrict__ dg,
+                                                                  float* __restrict__ partial) {
+  constexpr int SP = 16 * NT;
+  constexpr int NP = (SP * F13 / 2 + 63) / 64;
+  constexpr int NF = NT * NT * 4;
+  __shared__ float sCA[NF * 64];     // A operand of "A x":   A[s = 16 mi + c][s' = 16 i + 4 g + r]
+  __shared__ float sCT[NF * 64];     // A operand of "A^T x": A[s' = 16 i + 4 g + r][s = 16 mi + c]
+  __shared__ __attribute__((aligned(16))) float sbuf[BWD_WAVES * 2 * SP * XS];
+  static_assert(2 * SP * XS >= PART, "the per-wave staging buffer doubles as its reduction row");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int I = S * F13;
+  float* xb = sbuf + wave * 2 * SP * XS;
+  float* db = xb + SP * XS;
+  for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;
+  for (int q = wave; q < 2 * NF; q += BWD_WAVES) {            // fragment q of A (q < NF) or A^T
+    const int f = q % NF, mi = f / (NT * 4), i = (f / 4) % NT, r = f % 4;
+    const float v = a_elem(A, S, 16 * mi + c, 16 * i + 4 * g + r, q >= NF);
+    (q < NF ? sCA : sCT)[f * 64 + lane] = v;
+  }
+  __syncthreads();
+  auto ldA = [&](int mi, int i, int r) { return sCA[((mi * NT + i) * 4 + r) * 64 + lane]; };
+  auto ldT = [&](int mi, int i, int r) { return sCT[((mi * NT + i) * 4 + r) * 64 + lane]; };
+
+  float FW1[4], FW2T[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * g + r;
+    FW1[r] = (f < F13 && c < F13) ? W1[f * F13 + c] : 0.f;    // B operand of X W1:    W1[f][f' = c]
+    FW2T[r] = (f < F13 && c < F13) ? W2[c * F13 + f] : 0.f;   // B operand of dU2 W2^T: W2^T[f' = 4g+r][f = c]
+  }
+  const float bias1 = c < F13 ? b1[c] : 0.f;                   // H1 is [s][f] here: bias per column
+  PairMap<NP> map;
+  map.init(lane, I, SP * XS - 1);
+  const int npairs = (I + 1) / 2;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+
+  f32x4 dW1acc = zero4, dW2acc = zero4;
+  float db1acc = 0.f, db2acc = 0.f;
+  f32x2 xr[NP], dr[NP], gr[NP];
+  if (wave_id < ntiles) {
+    gload_pairs<NP>(xr, X + (size_t)wave_id * I, lane, I);
+    gload_pairs<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
+    gload_pairs<NP>(dr, dg + (size_t)wave_id * I, lane, I);
+  }
+  for (int tile = wave_id; tile < ntiles; tile += nwaves) {
+    asm volatile("" ::: "memory");                             // keep the fragment reads in LDS (no hoisting into VGPRs)
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (64 * k < npairs) {
+        xb[map.o0[k]] = xr[k][0];
+        xb[map.o1[k]] = xr[k][1];
+        db[map.o0[k]] = gr[k][0] > 0.f ? dr[k][0] : 0.f;       // dZ2 = dg * (g > 0)
+        db[map.o1[k]] = gr[k][1] > 0.f ? dr[k][1] : 0.f;
+      }
+    }
+    wave_lds_fence();
+    if (tile + nwaves < ntiles) {
+      const size_t nt = (size_t)(tile + nwaves);
+      gload_pairs<NP>(xr, X + nt * I, lane, I);
+      gload_pairs<NP>(gr, gact + nt * ld_g, lane, I);
+      gload_pairs<NP>(dr, dg + nt * I, lane, I);
+    }
+    // ---- recompute U1 [s][f'], H1 [s][f]
+    f32x4 U[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const f32x4 xv = *(const f32x4*)(xb + (16 * i + c) * XS + 4 * g);
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma16(xv[r], FW1[r], acc);
+      U[i] = acc;
+    }
+    f32x4 H1[NT];
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(ldA(mi, i, r), U[i][r], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s = 16 * mi + 4 * g + r;
+        H1[mi][r] = s < S ? fmaxf(acc[r] + bias1, 0.f) : 0.f;
+      }
+    }
+    // ---- dZ2 [s][f'] from the staged tile (pads are zero)
+    f32x4 dZ[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = db[(16 * i + 4 * g + r) * XS + c];
+        dZ[i][r] = v;
+        db2acc += v;
+      }
+    // ---- dU2 [s'][f'] = A^T dZ2 ; dW2 += H1^T dU2
+    f32x4 dU[NT];
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(ldT(mi, i, r), dZ[i][r], acc);
+      dU[mi] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dW2acc = mfma16(H1[i][r], dU[i][r], dW2acc);
+    // ---- dH1 [s'][f] = dU2 W2^T: through the wave's tile (dZ2 in it has been consumed)
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) db[(16 * i + 4 * g + r) * XS + c] = dU[i][r];
+    wave_lds_fence();
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const f32x4 dv = *(const f32x4*)(db + (16 * n + c) * XS + 4 * g);     // dU2[s' = 16 n + c][f' = 4 g + 0..3]
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma16(dv[r], FW2T[r], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = H1[n][r] > 0.f ? acc[r] : 0.f;                      // dZ1 = dH1 * (H1 > 0)
+        dZ[n][r] = v;
+        db1acc += v;
+      }
+    }
+    // ---- dU1 = A^T dZ1 ; dW1 += X^T dU1
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi) {
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(ldT(mi, i, r), dZ[i][r], acc);
+      dU[mi] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dW1acc = mfma16(xb[(16 * i + 4 * g + r) * XS + c], dU[i][r], dW1acc);
+  }
+
+  // ---- per-block reduction, one partial row per block (deterministic order)
+  float* red = sbuf;
+  __syncthreads();
+  float* mine = red + wave * PART;
+  for (int i = lane; i < PART; i += 64) mine[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    mine[(4 * g + r) * FP + c] = dW1acc[r];
+    mine[FP * FP + (4 * g + r) * FP + c] = dW2acc[r];
+  }
+  db1acc += __shfl_xor(db1acc, 16, 64);
+  db1acc += __shfl_xor(db1acc, 32, 64);
+  db2acc += __shfl_xor(db2acc, 16, 64);
+  db2acc += __shfl_xor(db2acc, 32, 64);
+  if (g == 0) {
+    mine[2 * FP * FP + c] = db1acc;
+    mine[2 * FP * FP + FP + c] = db2acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PART; i += blockDim.x) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < BWD_WAVES; ++w) t += red[w * PART + i];
+    partial[(size_t)blockIdx.x * PART + i] = t;
+  }
+}
+
+int bwd_grid(int ntiles) {
+  int gx = cdiv_i(ntiles, BWD_WAVES);
+  return gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+}
+
+}  // namespace
+
+size_t gcn32_bwd_partial_floats(int ntiles) { return (size_t)512 * PART; }
+
+int launch_gcn32_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+                     const float* W2, const float* b2, float* g, int ldg, hipStream_t st) {
+  const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
+  const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
+  int gx = cdiv_i(ntiles, FWD_WAVES);
+  gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+#define FCASE(NT)                                                                                                \
+  PROF_LAUNCH("gcn32_fwd_kernel<" #NT ">", fl, by, st,                                                           \
+              hipLaunchKernelGGL((gcn32_fwd_kernel<NT>), dim3(gx), dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, \
+                                 b2, g, ldg))
+  switch ((S + 15) / 16) {
+    case 1: FCASE(1); break;
+    case 2: FCASE(2); break;
+    case 3: FCASE(3); break;
+    case 4: FCASE(4); break;
+    default: return WGNN_ERR_UNSUPPORTED;
+  }
+#undef FCASE
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
+                     const float* W2, const float* g, int ldg, const float* dg, float* dW1, float* db1, float* dW2,
+                     float* db2, float* partial, hipStream_t st) {
+  const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
+  const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
+  const int gx = bwd_grid(ntiles);
+#define BCASE(NT)                                                                                                \
+  PROF_LAUNCH("gcn32_bwd_kernel<" #NT ">", fl, by, st,                                                           \
+              hipLaunchKernelGGL((gcn32_bwd_kernel<NT>), dim3(gx), dim3(64 * BWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, \
+                                 g, ldg, dg, partial))
+  switch ((S + 15) / 16) {
+    case 1: BCASE(1); break;
+    case 2: BCASE(2); break;
+    case 3: BCASE(3); break;
+    case 4: BCASE(4); break;
+    default: return WGNN_ERR_UNSUPPORTED;
+  }
+#undef BCASE
+  WGNN_CHECK_LAUNCH();
+  return launch_gcn_partial_reduce(partial, gx, dW1, db1, dW2, db2, nullptr, st);
+}
