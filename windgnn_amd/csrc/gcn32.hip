@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
 
 int bwd_grid(int ntiles) {
   int gx = cdiv_i(ntiles, BWD_WAVES);
-  return gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+  return gx < 1 ? 1 : (gx > 256 ? 256 : gx);   // one 12-wave block per CU, persistent over the tiles
 }
 
 }  // namespace

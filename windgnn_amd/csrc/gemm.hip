@@ -145,54 +145,66 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   int since = 0;
-  float va[NVA], vb[8];
+  // RS register stages: while step i is multiplied out of LDS stage i & 1, the operands of steps i+1 .. i+RS are in
+  // registers or in flight.  The 64-row tile (small M: few workgroups per CU to hide latency) takes two, the
+  // 128-row tile one (it is at 244 VGPRs).
+  constexpr int RS = MI == 1 ? 2 : 1;
+  float va[RS][NVA], vb[RS][8];
   if (kbeg < kend) {
-    fetch<false, NVA>(va, p, p.A, p.lda, p.a_kc, m0, p.M, kbeg, kend);
-    fetch<true, 8>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg, kend);
-    commit<NVA>(As2[0], va, p.a_kc);
-    commit<8>(Bs2[0], vb, p.b_kc);
-    if (kbeg + BK < kend) {
-      fetch<false, NVA>(va, p, p.A, p.lda, p.a_kc, m0, p.M, kbeg + BK, kend);
-      fetch<true, 8>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg + BK, kend);
-    }
+    fetch<false, NVA>(va[0], p, p.A, p.lda, p.a_kc, m0, p.M, kbeg, kend);
+    fetch<true, 8>(vb[0], p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg, kend);
+    commit<NVA>(As2[0], va[0], p.a_kc);
+    commit<8>(Bs2[0], vb[0], p.b_kc);
+#pragma unroll
+    for (int u = 0; u < RS; ++u)
+      if (kbeg + (1 + u) * BK < kend) {
+        fetch<false, NVA>(va[u], p, p.A, p.lda, p.a_kc, m0, p.M, kbeg + (1 + u) * BK, kend);
+        fetch<true, 8>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg + (1 + u) * BK, kend);
+      }
   }
   __syncthreads();
   int stg = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK, stg ^= 1) {
-    if (since == 512 / BK) {
+  for (int kq = kbeg; kq < kend; kq += RS * BK) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+    for (int u = 0; u < RS; ++u) {
+      const int k0 = kq + u * BK;
+      if (k0 >= kend) break;            // workgroup-uniform
+      if (since == 512 / BK) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          tot[i][j] += acc[i][j];
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
-      since = 0;
-    }
-    ++since;
-    if (k0 + BK < kend) {               // step k+1: registers (loaded during step k-1) -> the other LDS stage
-      commit<NVA>(As2[stg ^ 1], va, p.a_kc);
-      commit<8>(Bs2[stg ^ 1], vb, p.b_kc);
-    }
-    if (k0 + 2 * BK < kend) {           // step k+2: in flight under this step's MFMAs
-      fetch<false, NVA>(va, p, p.A, p.lda, p.a_kc, m0, p.M, k0 + 2 * BK, kend);
-      fetch<true, 8>(vb, p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + 2 * BK, kend);
-    }
-    const float* As = As2[stg];
-    const float* Bs = Bs2[stg];
+          for (int j = 0; j < 2; ++j) {
+            tot[i][j] += acc[i][j];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float b0 = Bs[(kk + lk) * LDT + wn + li];
-      const float b1 = Bs[(kk + lk) * LDT + wn + 32 + li];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const float a = As[(kk + lk) * LDT + wm + 32 * i + li];
-        acc[i][0] = mfma32(a, b0, acc[i][0]);
-        acc[i][1] = mfma32(a, b1, acc[i][1]);
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+        since = 0;
       }
+      ++since;
+      if (k0 + BK < kend) {             // step k+1: register stage u -> the other LDS stage
+        commit<NVA>(As2[stg ^ 1], va[u], p.a_kc);
+        commit<8>(Bs2[stg ^ 1], vb[u], p.b_kc);
+      }
+      if (k0 + (1 + RS) * BK < kend) {  // step k+1+RS: refill register stage u
+        fetch<false, NVA>(va[u], p, p.A, p.lda, p.a_kc, m0, p.M, k0 + (1 + RS) * BK, kend);
+        fetch<true, 8>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + (1 + RS) * BK, kend);
+      }
+      const float* As = As2[stg];
+      const float* Bs = Bs2[stg];
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float b0 = Bs[(kk + lk) * LDT + wn + li];
+        const float b1 = Bs[(kk + lk) * LDT + wn + 32 + li];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const float a = As[(kk + lk) * LDT + wm + 32 * i + li];
+          acc[i][0] = mfma32(a, b0, acc[i][0]);
+          acc[i][1] = mfma32(a, b1, acc[i][1]);
+        }
+      }
+      __syncthreads();                  // stage stg is free for step k+2; stage stg^1 is complete
+      stg ^= 1;
     }
-    __syncthreads();                    // stage stg is free for step k+2; stage stg^1 is complete
   }
 
   float* C = p.partial ? p.partial + (size_t)z * p.M * p.N : p.C;
