@@ -271,6 +271,46 @@ def test_full_size_properties_B4096(math):
         assert rel_to_max(gk.cpu(), go[k]) <= g_tol, k
 
 
+@pytest.mark.parametrize("S,T,B,H", [(34, 24, 1100, 102), (7, 24, 1100, 21), (20, 30, 900, 64), (34, 24, 1500, 128)])
+def test_exact_fp32_big_tile_gemms(S, T, B, H):
+    """Exact-fp32 mode at B*T >= 24576 switches GI, dg and dW_ih to the big-tile LDS-DMA GEMMs (csrc/gemm32.hip); two
+    half batches stay on the general kernel (csrc/gemm.hip).  The two routes must agree to fp32 rounding (Y per window,
+    gradients summed over the halves), and the big route must agree with the fp64 oracle (first shape)."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
+    dev = _dev()
+    assert B * T >= 24576 and (B // 2) * T < 24576
+    g = torch.Generator().manual_seed(5)
+    A = torch.rand(S, S, generator=g) / S
+    X = torch.rand(B, T, S, 13, generator=g)
+    dY = (torch.rand(B, T, H, generator=g) - 0.5) * 1e-3
+    p = orc.init_params(S, 13, H, seed=11)
+    model = _model_from(p, S, H, "f32")
+    params = [q.detach() for q in model.hot_path_parameters()]
+    Ad, Xd, dYd = A.to(dev), X.to(dev), dY.to(dev)
+
+    def run(Xs, dYs):
+        Y, stash, d = gcn_gru_forward_raw(Ad, Xs, params, model.math, want_stash=True)
+        grads = [torch.empty_like(q) for q in params]
+        gcn_gru_backward_raw(d, Ad, Xs, params, Y, dYs, stash, grads)
+        return Y, grads
+
+    Y, G = run(Xd, dYd)
+    h = B // 2
+    Y1, G1 = run(Xd[:h].contiguous(), dYd[:h].contiguous())
+    Y2, G2 = run(Xd[h:].contiguous(), dYd[h:].contiguous())
+    assert max_abs(Y[:h].cpu(), Y1.cpu()) <= 2e-6 and max_abs(Y[h:].cpu(), Y2.cpu()) <= 2e-6
+    for k, a, b, c in zip(PARAM_KEYS, G, G1, G2):
+        assert rel_to_max((b + c).cpu(), a.cpu()) <= 1e-5, k
+    if S == 34 and H == 102:
+        p64 = {k: v.double() for k, v in p.items()}
+        Yo, cache = orc.forward(A.double(), X.double(), p64)
+        go = orc.backward(A.double(), X.double(), p64, Yo, cache, dY.double())
+        assert max_abs(Y.cpu(), Yo) <= 1e-5
+        for k, gk in zip(PARAM_KEYS, G):
+            assert rel_to_max(gk.cpu(), go[k]) <= 1e-5, k
+
+
 def test_backward_in_two_parts_equals_one_call():
     """wgnn_bwd_part(1) then (2) must give bit-identical gradients to wgnn_bwd (the data-parallel overlap path)."""
     from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw

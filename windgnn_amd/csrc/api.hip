@@ -19,7 +19,9 @@ struct Layout {
   int sk_ih, sk_hh;
   // which kernels run: the fp16-plane family needs the dense LDS-resident GCN and the register-resident GRU;
   // shapes beyond the fast kernels (CSR adjacency, wide hidden state) use general.hip in exact fp32
-  bool x3, gen_gcn, gen_gru;
+  bool x3, gen_gcn, gen_gru, g32;
+  int hq;
+  size_t ws_hprev;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
   bool dghn;                                     // fast f16x3 recurrence: only the n third of dGH is stored (dGHn planes)
   int hn, msplit, m_hh;                          // its row width, its first GEMM row, GEMM rows of the dW_hh product
@@ -44,7 +46,7 @@ Layout make_layout(const wgnn_dims* d) {
   const bool x3 = L.x3;
   L.BT = (size_t)d->B * d->T;
   L.I = (size_t)d->S * d->F;
-  L.Ip = rup(L.I + (x3 ? 1 : 0), 32);       // f16x3: room for the ones column at index I
+  L.Ip = rup(L.I + 1, 32);                  // room for the ones column at index I
   L.H = d->H;
   L.Hp = x3 ? (size_t)grux_hp(d->H) : 0;
   L.G3 = 3 * (size_t)d->H;
@@ -52,8 +54,10 @@ Layout make_layout(const wgnn_dims* d) {
   L.np_g3 = pgemm_nt_np((int)L.G3);
   L.np_i = pgemm_nt_np((int)L.I);
   auto al = [](size_t x) { return align_up(x, 64); };
-  const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : 0;   // 2 planes of halfs = that many floats
-  const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : 0;
+  // exact fp32 at large B*T: the big-tile GEMMs of gemm32.hip on zero-padded copies of W_ih / W_ih^T
+  L.g32 = !x3 && !L.gen_gcn && !L.gen_gru && gemm32_supported(L.BT, (int)L.Ip, (int)L.Gp);
+  const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : (L.g32 ? (size_t)gemm32_nt_rows((int)L.G3) * L.Ip : 0);   // 2 planes of halfs = that many floats
+  const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : (L.g32 ? (size_t)gemm32_nt_rows((int)L.I) * L.Gp : 0);
   constexpr size_t HDR = WGNN_STATUS_BYTES / sizeof(float);   // status block at the start of the workspace
   size_t o = HDR;
   L.ws_GI = o; o += al(L.BT * L.Gp);   // rows padded to 128-B multiples
@@ -87,8 +91,10 @@ Layout make_layout(const wgnn_dims* d) {
     L.sk_hh = pick_splitk(L.BT, pgemm_tn_tiles(L.m_hh, (int)L.H + 1), 256, 64);
   } else {
     // K chunks of at least 128 rows (B*T = 6144 at BASELINE configs[1]: with 256-row chunks the dW_hh product had 72 workgroups)
-    L.sk_ih = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.I + 1, 128), 1024, 128);
-    L.sk_hh = pick_splitk(L.BT, cdiv_i((int)L.G3, 128) * cdiv_i((int)L.H + 1, 128), 1024, 128);
+    L.sk_ih = L.g32 ? pick_splitk(L.BT, gemm32_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64)   // one workgroup per CU
+                    : pick_splitk(L.BT, gemm_f32_tiles((int)L.G3, (int)L.I + 1), 1024, 128);
+    L.sk_hh = L.g32 ? pick_splitk(L.BT, gemm32_tn_tiles((int)L.G3, (int)L.H + 1), 256, 64)
+                    : pick_splitk(L.BT, gemm_f32_tiles((int)L.G3, (int)L.H + 1), 1024, 128);
   }
   size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
   size_t part_hh = (size_t)L.sk_hh * L.G3 * (L.H + 1);
@@ -106,6 +112,8 @@ Layout make_layout(const wgnn_dims* d) {
     if (L.gen_gcn) a = gcn_csr_bwd_partial_floats();
     L.ws_gcnpart = o; o += al(a > b ? a : b);
   }
+  L.hq = (int)rup(L.H + 1, 16);
+  L.ws_hprev = o; o += al(L.g32 ? L.BT * (size_t)L.hq : 0);    // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
   L.ws_du = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.ws_dhz = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
   L.ws_dhw = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
@@ -245,12 +253,19 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
                          (int)L.Ip, st);
   }
   if (rc != WGNN_OK) return rc;
-  GemmArgs ga = {};
-  ga.A = g; ga.lda = (int)L.Ip; ga.a_kcontig = 1;
-  ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
-  ga.C = GI; ga.ldc = (int)L.Gp; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
-  ga.bias = p->b_ih; ga.splitk = 1;
-  rc = launch_gemm_f32(ga, st);
+  if (L.g32) {       // GI = [g|1] [W_ih|b_ih]^T
+    float* wp = ws + L.ws_planes_f;
+    rc = launch_pad_weight(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, wp, gemm32_nt_rows((int)L.G3), (int)L.Ip, st);
+    if (rc != WGNN_OK) return rc;
+    rc = launch_gemm32_nt(g, (int)L.Ip, (int)L.BT, (int)L.Ip, wp, GI, (int)L.Gp, (int)L.G3, st);
+  } else {
+    GemmArgs ga = {};
+    ga.A = g; ga.lda = (int)L.Ip; ga.a_kcontig = 1;
+    ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
+    ga.C = GI; ga.ldc = (int)L.Gp; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
+    ga.bias = p->b_ih; ga.splitk = 1;
+    rc = launch_gemm_f32(ga, st);
+  }
   if (rc != WGNN_OK) return rc;
   if (L.gen_gru)
     rc = launch_gru_gen_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, ws + L.ws_gh, st);
@@ -418,34 +433,52 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
   }
   if (do_wg) {
     // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
-    GemmArgs a = {};
-    a.A = dGH; a.lda = (int)L.Gp; a.a_kcontig = 0;
-    a.B = Y; a.ldb = (int)L.H; a.b_kcontig = 0; a.ones_col = 1; a.shift_T = d->T;
-    a.M = (int)L.G3; a.N = (int)L.H + 1; a.K = (int)L.BT;
-    a.splitk = L.sk_hh; a.partial = part;
-    rc = launch_gemm_f32(a, st);
+    if (L.g32) {
+      float* hp = ws + L.ws_hprev;
+      rc = launch_hprev_pad(Y, d->B, d->T, d->H, hp, L.hq, st);
+      if (rc != WGNN_OK) return rc;
+      rc = launch_gemm32_tn(dGH, (int)L.Gp, hp, L.hq, (int)L.BT, L.sk_hh, part, (int)L.G3, (int)L.H + 1, st);
+    } else {
+      GemmArgs a = {};
+      a.A = dGH; a.lda = (int)L.Gp; a.a_kcontig = 0;
+      a.B = Y; a.ldb = (int)L.H; a.b_kcontig = 0; a.ones_col = 1; a.shift_T = d->T;
+      a.M = (int)L.G3; a.N = (int)L.H + 1; a.K = (int)L.BT;
+      a.splitk = L.sk_hh; a.partial = part;
+      rc = launch_gemm_f32(a, st);
+    }
     if (rc != WGNN_OK) return rc;
-    rc = launch_splitk_reduce(part, L.sk_hh, a.M, a.N, g->w_hh, (int)L.H, (int)L.H, g->b_hh, nullptr, st);
+    rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, nullptr, st);
     if (rc != WGNN_OK) return rc;
     // dW_ih = dGI^T g, db_ih = dGI^T 1
-    GemmArgs b = {};
-    b.A = dGI; b.lda = (int)L.Gp; b.a_kcontig = 0;
-    b.B = gact; b.ldb = (int)L.Ip; b.b_kcontig = 0; b.ones_col = 1;
-    b.M = (int)L.G3; b.N = (int)L.I + 1; b.K = (int)L.BT;
-    b.splitk = L.sk_ih; b.partial = part;
-    rc = launch_gemm_f32(b, st);
+    if (L.g32) {       // g carries its ones column (gcn32_fwd)
+      rc = launch_gemm32_tn(dGI, (int)L.Gp, gact, (int)L.Ip, (int)L.BT, L.sk_ih, part, (int)L.G3, (int)L.I + 1, st);
+    } else {
+      GemmArgs b = {};
+      b.A = dGI; b.lda = (int)L.Gp; b.a_kcontig = 0;
+      b.B = gact; b.ldb = (int)L.Ip; b.b_kcontig = 0; b.ones_col = 1;
+      b.M = (int)L.G3; b.N = (int)L.I + 1; b.K = (int)L.BT;
+      b.splitk = L.sk_ih; b.partial = part;
+      rc = launch_gemm_f32(b, st);
+    }
     if (rc != WGNN_OK) return rc;
-    rc = launch_splitk_reduce(part, L.sk_ih, b.M, b.N, g->w_ih, (int)L.I, (int)L.I, g->b_ih, nullptr, st);
+    rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, nullptr, st);
     if (rc != WGNN_OK) return rc;
   }
   if (!do_gcn) return WGNN_OK;
   {
     // dg = dGI W_ih
-    GemmArgs c = {};
-    c.A = dGI; c.lda = (int)L.Gp; c.a_kcontig = 1;
-    c.B = p->w_ih; c.ldb = (int)L.I; c.b_kcontig = 0;
-    c.C = dg; c.ldc = (int)L.I; c.M = (int)L.BT; c.N = (int)L.I; c.K = (int)L.G3; c.splitk = 1;
-    rc = launch_gemm_f32(c, st);
+    if (L.g32) {
+      float* wt = ws + L.ws_planes_b;     // (W_ih^T) [I -> padded][Gp]
+      rc = launch_pad_weight(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, wt, gemm32_nt_rows((int)L.I), (int)L.Gp, st);
+      if (rc != WGNN_OK) return rc;
+      rc = launch_gemm32_nt(dGI, (int)L.Gp, (int)L.BT, (int)L.Gp, wt, dg, (int)L.I, (int)L.I, st);
+    } else {
+      GemmArgs c = {};
+      c.A = dGI; c.lda = (int)L.Gp; c.a_kcontig = 1;
+      c.B = p->w_ih; c.ldb = (int)L.I; c.b_kcontig = 0;
+      c.C = dg; c.ldc = (int)L.I; c.M = (int)L.BT; c.N = (int)L.I; c.K = (int)L.G3; c.splitk = 1;
+      rc = launch_gemm_f32(c, st);
+    }
     if (rc != WGNN_OK) return rc;
   }
   if (L.gen_gcn)

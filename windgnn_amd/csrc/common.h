@@ -94,6 +94,18 @@ struct GemmArgs {
   float* partial;
 };
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st);
+void gemm_f32_tile(int M, int N, int* bm, int* bn);
+int gemm_f32_tiles(int M, int N);
+// gemm32.hip: big-tile exact-fp32 GEMMs for large B*T (operands padded and 16-byte aligned)
+bool gemm32_supported(size_t BT, int Kp_f, int Kp_b);
+int gemm32_nt_rows(int N);
+int launch_pad_weight(const float* W, int R, int C, int transpose, const float* bias, float* out, int Ro, int Co,
+                      hipStream_t st);
+int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, hipStream_t st);
+int gemm32_tn_tiles(int Mo, int No);
+int launch_hprev_pad(const float* Y, int B, int T, int H, float* out, int ld, hipStream_t st);
+int launch_gemm32_tn(const float* A, int lda, const float* B, int ldb, int K, int splitk, float* P, int Mo, int No,
+                     hipStream_t st);
 // C[m*ldc+n] = sum_z partial[z][m][n] for n < ncols_main; bias_out[m] = sum_z partial[z][m][N-1] if bias_out
 int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* C, int ldc,
                          int ncols_main, float* bias_out, const float* scales /*nullable: *= scales[1]*/,

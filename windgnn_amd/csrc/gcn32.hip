@@ -179,6 +179,9 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcn32_fwd_kernel(int ntiles, i
           else if (e < I) dst[e] = v[0];
         }
       }
+      // the K padding of the row: a ones column at I (the bias column's partner in the big-tile GEMMs of gemm32.hip,
+      // db_ih in dGI^T [g|1]), zeros after it
+      if (lane < ldg - I) dst[I + lane] = lane == 0 ? 1.f : 0.f;
     }
   }
 }

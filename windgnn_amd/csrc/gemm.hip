@@ -7,10 +7,11 @@
 // so that fragment reads are conflict-free.  Either operand may be K-contiguous or M/N-contiguous
 // in global memory.  Exact fp32 (bitwise an fmaf chain along k).
 #include "common.h"
+#include <cstdio>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+constexpr int BK = 16, LDT = 128 + 4;
 
 struct GemmP {
   const float* A; int lda; int a_kc;
@@ -109,57 +110,59 @@ __device__ __forceinline__ void commit(float* T, const float (&v)[NV], int kcont
   }
 }
 
-// MI: 32-row MFMA tiles per wave along M: 2 = the 128 x 128 tile; 1 = a 64 x 128 tile for products whose 128-row
-// tiling would leave most CUs without a workgroup (small batches: M = B*T = 6144 at BASELINE configs[1])
-template <int MI>
+// MI x NJ: 32 x 32 MFMA tiles per wave along M and N; the workgroup tile is 64 MI x 64 NJ.  2 x 2 = the 128 x 128
+// tile; the 64-wide forms serve products whose 128-wide tiling would pad a dimension by more than the 64-wide one
+// (N = 306 -> 320 instead of 384, 442 -> 448 instead of 512) or leave CUs without a workgroup (small batches:
+// M = B*T = 6144 at BASELINE configs[1])
+template <int MI, int NJ>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
-  constexpr int BMv = 64 * MI, NVA = 4 * MI;
+  constexpr int BMv = 64 * MI, BNv = 64 * NJ, NVA = 4 * MI, NVB = 4 * NJ;
   // two LDS stages: step k is multiplied out of stage k & 1 while step k+1's operands (loaded into registers during
   // step k-1) are committed to the other stage and step k+2's loads are issued -- ONE barrier per k step
   __shared__ __attribute__((aligned(16))) float As2[2][BK * LDT];
   __shared__ __attribute__((aligned(16))) float Bs2[2][BK * LDT];
-  const int m0 = blockIdx.x * BMv, n0 = blockIdx.y * BN;
+  const int m0 = blockIdx.x * BMv, n0 = blockIdx.y * BNv;
   const int z = blockIdx.z;
   const int kbeg = z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * 32 * MI, wn = (wave & 1) * 32 * NJ;
   const int li = lane & 31, lk = lane >> 5;
 
-  f32x16 acc[MI][2];
+  f32x16 acc[MI][NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // Two-level summation: the MFMA chain over k is sequential, so every 512 k the running tile is folded into
   // `tot` (error grows with sqrt(512) + sqrt(K/512) instead of sqrt(K); K is 53 248 in the 4096-station
   // input projection).  For K <= 512 this is bitwise the single chain.
-  f32x16 tot[MI][2];
+  f32x16 tot[MI][NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   int since = 0;
   // RS register stages: while step i is multiplied out of LDS stage i & 1, the operands of steps i+1 .. i+RS are in
   // registers or in flight.  The 64-row tile (small M: few workgroups per CU to hide latency) takes two, the
   // 128-row tile one (it is at 244 VGPRs).
-  constexpr int RS = MI == 1 ? 2 : 1;
-  float va[RS][NVA], vb[RS][8];
+  constexpr int RS = MI * NJ == 4 ? 1 : 2;
+  float va[RS][NVA], vb[RS][NVB];
   if (kbeg < kend) {
     fetch<false, NVA>(va[0], p, p.A, p.lda, p.a_kc, m0, p.M, kbeg, kend);
-    fetch<true, 8>(vb[0], p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg, kend);
+    fetch<true, NVB>(vb[0], p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg, kend);
     commit<NVA>(As2[0], va[0], p.a_kc);
-    commit<8>(Bs2[0], vb[0], p.b_kc);
+    commit<NVB>(Bs2[0], vb[0], p.b_kc);
 #pragma unroll
     for (int u = 0; u < RS; ++u)
       if (kbeg + (1 + u) * BK < kend) {
         fetch<false, NVA>(va[u], p, p.A, p.lda, p.a_kc, m0, p.M, kbeg + (1 + u) * BK, kend);
-        fetch<true, 8>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg + (1 + u) * BK, kend);
+        fetch<true, NVB>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, kbeg + (1 + u) * BK, kend);
       }
   }
   __syncthreads();
@@ -173,7 +176,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < NJ; ++j) {
             tot[i][j] += acc[i][j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -183,23 +186,24 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
       ++since;
       if (k0 + BK < kend) {             // step k+1: register stage u -> the other LDS stage
         commit<NVA>(As2[stg ^ 1], va[u], p.a_kc);
-        commit<8>(Bs2[stg ^ 1], vb[u], p.b_kc);
+        commit<NVB>(Bs2[stg ^ 1], vb[u], p.b_kc);
       }
       if (k0 + (1 + RS) * BK < kend) {  // step k+1+RS: refill register stage u
         fetch<false, NVA>(va[u], p, p.A, p.lda, p.a_kc, m0, p.M, k0 + (1 + RS) * BK, kend);
-        fetch<true, 8>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + (1 + RS) * BK, kend);
+        fetch<true, NVB>(vb[u], p, p.B, p.ldb, p.b_kc, n0, p.N, k0 + (1 + RS) * BK, kend);
       }
       const float* As = As2[stg];
       const float* Bs = Bs2[stg];
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 2) {
-        const float b0 = Bs[(kk + lk) * LDT + wn + li];
-        const float b1 = Bs[(kk + lk) * LDT + wn + 32 + li];
+        float b[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = Bs[(kk + lk) * LDT + wn + 32 * j + li];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const float a = As[(kk + lk) * LDT + wm + 32 * i + li];
-          acc[i][0] = mfma32(a, b0, acc[i][0]);
-          acc[i][1] = mfma32(a, b1, acc[i][1]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(a, b[j], acc[i][j]);
         }
       }
       __syncthreads();                  // stage stg is free for step k+2; stage stg^1 is complete
@@ -212,7 +216,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int col = n0 + wn + 32 * j + li;
       if (col >= p.N) continue;
       const float bv = (p.bias && !p.partial) ? p.bias[col] : 0.f;
@@ -252,6 +256,23 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
 
 }  // namespace
 
+// Workgroup tile for an M x N product.  Measured (B = 4096 / 256, S = 34, H = 102): with thousands of tiles the 128 x 128
+// form wins although it pads N = 306 to 384 (368 vs 408 us at 128 x 64: fewer operand bytes per MFMA); with few tiles the
+// narrow forms win (M = 6144: 43 vs 59 us) -- they pad less and give every CU several workgroups.
+void gemm_f32_tile(int M, int N, int* bm, int* bn) {
+  if (cdiv_i(M, 128) * cdiv_i(N, 128) >= 1024) {
+    *bm = *bn = 128;
+    return;
+  }
+  *bn = cdiv_i(N, 64) * 64 < cdiv_i(N, 128) * 128 ? 64 : 128;
+  *bm = (cdiv_i(M, 64) * 64 < cdiv_i(M, 128) * 128 || cdiv_i(M, 128) * cdiv_i(N, *bn) < 512) ? 64 : 128;
+}
+int gemm_f32_tiles(int M, int N) {
+  int bm, bn;
+  gemm_f32_tile(M, N, &bm, &bn);
+  return cdiv_i(M, bm) * cdiv_i(N, bn);
+}
+
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
   GemmP p;
   p.A = g.A; p.lda = g.lda; p.a_kc = g.a_kcontig;
@@ -263,13 +284,22 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
   p.partial = g.partial;
   const double fl = 2.0 * g.M * (double)g.N * g.K;
   const double by = 4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N * p.splitk);
-  // 64-row tiles when the 128-row tiling would not give every CU a workgroup
-  if (cdiv_i(g.M, BM) * cdiv_i(g.N, BN) * p.splitk < 256) {
-    dim3 grid(cdiv_i(g.M, 64), cdiv_i(g.N, BN), p.splitk);
-    PROF_LAUNCH("gemm_f32_kernel<64>", fl, by, st, hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, p));
+  int bm, bn;
+  gemm_f32_tile(g.M, g.N, &bm, &bn);
+  if (bm == 128 && cdiv_i(g.M, 128) * cdiv_i(g.N, bn) * p.splitk < 256) bm = 64;   // a split-K chosen elsewhere
+  dim3 grid(cdiv_i(g.M, bm), cdiv_i(g.N, bn), p.splitk);
+  // profile name: tile and operand forms ([kk] = both K-contiguous, [kn], [tn] = A given transposed)
+  char name[64];
+  snprintf(name, sizeof name, "gemm_f32_kernel<%d,%d>[%s%s%s]", bm, bn, g.a_kcontig ? (g.b_kcontig ? "kk" : "kn") : "tn",
+           g.ones_col ? ",ones" : "", g.shift_T > 0 ? ",shift" : "");
+  if (bm == 128 && bn == 128) {
+    PROF_LAUNCH(name, fl, by, st, hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), grid, dim3(256), 0, st, p));
+  } else if (bm == 128) {
+    PROF_LAUNCH(name, fl, by, st, hipLaunchKernelGGL((gemm_f32_kernel<2, 1>), grid, dim3(256), 0, st, p));
+  } else if (bn == 128) {
+    PROF_LAUNCH(name, fl, by, st, hipLaunchKernelGGL((gemm_f32_kernel<1, 2>), grid, dim3(256), 0, st, p));
   } else {
-    dim3 grid(cdiv_i(g.M, BM), cdiv_i(g.N, BN), p.splitk);
-    PROF_LAUNCH("gemm_f32_kernel", fl, by, st, hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, st, p));
+    PROF_LAUNCH(name, fl, by, st, hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, dim3(256), 0, st, p));
   }
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;

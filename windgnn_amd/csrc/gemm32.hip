@@ -1,0 +1,372 @@
+// Exact-fp32 GEMMs for large B*T (WGNN_MATH_F32): the GRU input projection, its backward and dW_ih on
+// v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 with the structure of the plane GEMMs (pgemm.hip): ONE large workgroup
+// per CU, operands staged by LDS-DMA (global_load_lds_dwordx4) exactly as they lie in HBM into a two-stage ring,
+// fragments read with wide LDS loads, no per-element bounds code in the main loop.  That needs operands whose rows are
+// 16-byte aligned and whose K extent is padded with finite values: g [B*T][Ip] (ones column at I, zeros after: written by
+// gcn32_fwd), dGI [B*T][Gp] (zero padding written by the recurrences' backward) and zero-padded copies of W_ih / W_ih^T
+// (pad_weight_kernel below, two ~3 us launches per step).  fp32 MFMA sustains 149 TFLOP/s here (tools/mfma_rate.hip);
+// the register-staged general kernel of gemm.hip (kept for small B*T, dW_hh and the wide-GRU paths) reaches 72.
+//
+//   NT  C[M][N] = A[M][Kp] . Bp[N][Kp]^T      GI = [g|1] [W_ih|b_ih]^T,   dg = dGI (W_ih^T)^T
+//   TN  P[z][Mo][No] = sum_k A[k][m] B[k][n]  dW_ih|db_ih = dGI^T [g|1]   (split-K, reduced by splitk_reduce_kernel)
+#include <string>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+// ------------------------------------------------------------------------------------------------
+// NT.  8 waves = 4 (M) x 2 (N); wave tile 32 x 32 T32, workgroup tile 128 x 64 T32; K step 32 = one 128-byte LDS row.
+// A k group of 8 = two 16-byte chunks: lane (i, kh) of the 32x32x2 MFMA reads chunk 2 kk + kh of row i as ONE
+// ds_read_b128; its element jj is the operand of MFMA jj, whose two k slots are therefore k = 8 kk + jj and 8 kk + 4 + jj
+// -- any bijection works as long as A and B agree.  The 16-byte chunks of a row are XOR-swizzled by (row >> 1) & 7
+// (applied on the DMA source address), which makes the 16 rows x 16 B of a quarter-wave hit 16 different bank groups.
+constexpr int G_BM = 128, G_WAVES = 8;
+
+template <int T32>
+__global__ void __launch_bounds__(64 * G_WAVES) gemm32_nt_kernel(const float* __restrict__ A, int lda, int M, int Kp,
+                                                               const float* __restrict__ Bp, float* __restrict__ C,
+                                                               int ldc, int N, int nm) {
+  constexpr int BN = 64 * T32;
+  constexpr int A_BYTES = G_BM * 128, STAGE = A_BYTES + BN * 128;
+  constexpr int AP = G_BM / 8, BP = BN / 8;                      // 1 KB pieces: 8 rows x 128 B
+  constexpr int NPIECE = AP + BP, NIT = (NPIECE + G_WAVES - 1) / G_WAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int mt = blockIdx.x % nm, sl = blockIdx.x / nm;
+  const int m0 = mt * G_BM, n0 = sl * BN;
+
+  f32x16 acc[T32];
+#pragma unroll
+  for (int j = 0; j < T32; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const float* src[NIT];
+  int dst[NIT];
+  bool on[NIT];
+  {
+    const int r8 = lane >> 3, pos = lane & 7;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int p = wave + G_WAVES * it;
+      on[it] = p < NPIECE;                                        // wave-uniform
+      const int pp = on[it] ? p : 0;
+      const bool isA = pp < AP;
+      const int blk = isA ? pp : pp - AP;
+      const int row = 8 * blk + r8;
+      const int chunk = pos ^ ((row >> 1) & 7);
+      if (isA) src[it] = A + (size_t)min(m0 + row, M - 1) * lda + 4 * chunk;   // rows past M: computed, never stored
+      else src[it] = Bp + (size_t)(n0 + row) * Kp + 4 * chunk;
+      dst[it] = (isA ? 0 : A_BYTES) + blk * 1024;
+    }
+  }
+  auto dma_stage = [&](char* st, int kt) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (on[it]) __builtin_amdgcn_global_load_lds((glb_void*)(src[it] + 32 * kt), (lds_void*)(st + dst[it]), 16, 0, 0);
+  };
+
+  const int li = lane & 31, kh = lane >> 5, sw = (li >> 1) & 7;
+  const int a_row = (32 * wm + li) * 128, b_row = A_BYTES + (32 * T32 * wn + li) * 128;
+  auto compute = [&](const char* cur) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int co = ((2 * kk + kh) ^ sw) << 4;
+      const f32x4 a = *(const f32x4*)(cur + a_row + co);
+      f32x4 b[T32];
+#pragma unroll
+      for (int j = 0; j < T32; ++j) b[j] = *(const f32x4*)(cur + b_row + j * 32 * 128 + co);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int j = 0; j < T32; ++j) acc[j] = mfma32(a[jj], b[j][jj], acc[j]);
+    }
+  };
+
+  const int nk = Kp / 32;
+  dma_stage(smem, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // stage kt visible to all waves, stage kt-1 no longer being read
+    if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kt + 1);
+    compute(smem + (kt & 1) * STAGE);
+  }
+
+#pragma unroll
+  for (int j = 0; j < T32; ++j) {
+    const int col = n0 + 32 * T32 * wn + 32 * j + li;
+    if (col >= N) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (row < M) C[(size_t)row * ldc + col] = acc[j][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN (split-K).  8 waves = 4 (M) x 2 (N); wave tile 80 x 16 T16 of v_mfma_f32_16x16x4_f32, workgroup tile 320 x 32 T16 of
+// one K chunk.  Both operands are K-strided in memory: a stage (32 k rows) is staged row-major as it lies in HBM and
+// lane (i, kq) of the MFMA reads element i of row 4 kk + kq directly (ds_read_b32).  The LDS row pitch is the tile
+// width + 16 floats, i.e. 16 or 48 (mod 64): the four rows one read touches then fall into four different 16-bank
+// windows.  The DMA image is linear, so the 16 pad floats of a row are written too (with the row's first chunk).
+constexpr int T_BM = 320, T_BK = 32;
+
+template <int T16>
+__global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __restrict__ A, int lda,
+                                                               const float* __restrict__ B, int ldb, int K, int kchunk,
+                                                               int splitk, float* __restrict__ P, int Mo, int No,
+                                                               int nNb, int ntiles) {
+  constexpr int WN = 16 * T16, BN = 2 * WN;
+  constexpr int PA = T_BM + 16, PB = BN + 16;                     // LDS row pitches (floats)
+  constexpr int A_BYTES = T_BK * PA * 4, STAGE = A_BYTES + T_BK * PB * 4;
+  constexpr int AP = PA / 8, BP = PB / 8;                         // 1 KB pieces
+  constexpr int NPIECE = AP + BP, NIT = (NPIECE + G_WAVES - 1) / G_WAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  // blocks {b, b+8, ...} share an XCD: they are the tiles of ONE K chunk, so the chunk's rows cross HBM -> L2 once
+  const int id = blockIdx.x;
+  const int z = (id / (8 * ntiles)) * 8 + id % 8, tile = (id / 8) % ntiles;
+  if (z >= splitk) return;
+  const int m0 = (tile / nNb) * T_BM, n0 = (tile % nNb) * BN;
+  const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
+
+  f32x4 acc[5][T16];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < T16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA plan: piece p of the stage image = bytes [1024 p, 1024 p + 1024); lane -> (row, column) through the pitch
+  int roff[NIT], coff[NIT], dst[NIT];     // row within the stage, column offset in floats (already + m0 / n0)
+  bool on[NIT], isA[NIT];
+  const int wa = min(T_BM, lda - m0), wb = min(BN, ldb - n0);      // columns that exist in memory
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int p = wave + G_WAVES * it;
+    on[it] = p < NPIECE;
+    const int pp = on[it] ? p : 0;
+    isA[it] = pp < AP;
+    const int q = isA[it] ? pp : pp - AP;
+    const int pitch = isA[it] ? PA : PB;
+    const int f = 256 * q + 4 * lane;                              // float index in the operand's stage image
+    const int row = f / pitch, col = f % pitch;
+    roff[it] = row;
+    coff[it] = isA[it] ? m0 + (col < wa ? col : 0) : n0 + (col < wb ? col : 0);
+    dst[it] = (isA[it] ? 0 : A_BYTES) + q * 1024;
+  }
+  auto dma_stage = [&](char* st, int k0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (on[it]) {
+        const int k = min(k0 + roff[it], K - 1);                   // rows past the chunk are zeroed below
+        const float* src = isA[it] ? A + (size_t)k * lda + coff[it] : B + (size_t)k * ldb + coff[it];
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + dst[it]), 16, 0, 0);
+      }
+  };
+
+  const int li = lane & 15, kq = lane >> 4;
+  const int a_off = (kq * PA + 80 * wm + li) * 4, b_off = A_BYTES + (kq * PB + WN * wn + li) * 4;
+  auto compute = [&](const char* cur) {
+#pragma unroll
+    for (int kk = 0; kk < T_BK / 4; ++kk) {
+      float a[5], b[T16];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) a[i] = *(const float*)(cur + a_off + (4 * kk * PA + 16 * i) * 4);
+#pragma unroll
+      for (int j = 0; j < T16; ++j) b[j] = *(const float*)(cur + b_off + (4 * kk * PB + 16 * j) * 4);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < T16; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    }
+  };
+
+  const int nk = (kend - kbeg + T_BK - 1) / T_BK;
+  if (nk > 0) dma_stage(smem, kbeg);
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // stage kt landed for all waves, stage kt-1 no longer being read
+    const int live = kend - (kbeg + kt * T_BK);                    // rows of this stage inside the chunk
+    if (live < T_BK) {                   // K tail (last stage of the last chunk only): zero A's dead rows
+      for (int e = tid; e < (T_BK - live) * PA; e += 64 * G_WAVES) ((float*)cur)[live * PA + e] = 0.f;
+      __syncthreads();
+    }
+    if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kbeg + (kt + 1) * T_BK);
+    compute(cur);
+  }
+
+  float* Pz = P + (size_t)z * Mo * No;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < T16; ++j) {
+      const int col = n0 + WN * wn + 16 * j + li;
+      if (col >= No) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 80 * wm + 16 * i + 4 * kq + r;
+        if (row < Mo) Pz[(size_t)row * No + col] = acc[i][j][r];
+      }
+    }
+}
+
+// out[Ro][Co] = zero-padded copy of W[R][C] (transpose: of W^T); bias, if given, goes to column C (the ones column's
+// partner) of the non-transposed copy.
+__global__ void pad_weight_kernel(const float* __restrict__ W, int R, int C, int transpose,
+                                  const float* __restrict__ bias, float* __restrict__ out, int Ro, int Co) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Ro * Co) return;
+  const int r = (int)(idx / Co), c = (int)(idx % Co);
+  float v = 0.f;
+  if (transpose) {
+    if (r < C && c < R) v = W[(size_t)c * C + r];
+  } else if (r < R) {
+    if (c < C) v = W[(size_t)r * C + c];
+    else if (c == C && bias) v = bias[r];
+  }
+  out[idx] = v;
+}
+
+// Hp[B*T][ld] = [Hprev | 1 | 0...]: row (b, t) = Y row (b, t-1), zero at t = 0 -- the B operand of dW_hh|db_hh = dGH^T [Hprev|1]
+// with 16-byte aligned rows (Y's rows are H floats long).  One thread per 4 output floats.
+__global__ void hprev_pad_kernel(const float* __restrict__ Y, size_t BT, int T, int H, float* __restrict__ out, int ld) {
+  const int q4 = ld / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= BT * q4) return;
+  const size_t bt = idx / q4;
+  const int c = 4 * (int)(idx % q4);
+  const bool live = (bt % T) != 0;
+  const float* src = Y + (live ? bt - 1 : 0) * H;
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = c + j < H ? (live ? src[c + j] : 0.f) : (c + j == H ? 1.f : 0.f);
+  *(f32x4*)(out + bt * ld + c) = v;
+}
+
+void nt_shape(int N, int& nsl, int& T) {
+  const int t32 = cdiv_i(N, 32);
+  nsl = cdiv_i(t32, 14);
+  T = cdiv_i(cdiv_i(t32, nsl), 2);       // <= 7: 2 x 56 KB of B + 2 x 16 KB of A fill the CU's LDS
+}
+
+template <int T32>
+int launch_nt_t(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, int nsl,
+                hipStream_t st) {
+  const int nm = cdiv_i(M, G_BM);
+  const size_t smem = 2 * (size_t)(G_BM + 64 * T32) * 128;
+  static std::atomic<unsigned long long> done{0};
+  if (ensure_dyn_smem((const void*)gemm32_nt_kernel<T32>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  static const std::string name = "gemm32_nt_kernel<" + std::to_string(T32) + ">";
+  const double fl = 2.0 * M * (double)N * Kp;
+  const double by = 4.0 * ((double)M * Kp + (double)N * Kp + (double)M * N);
+  PROF_LAUNCH(name.c_str(), fl, by, st,
+              hipLaunchKernelGGL(gemm32_nt_kernel<T32>, dim3(nm * nsl), dim3(64 * G_WAVES), smem, st, A, lda, M, Kp, Bp,
+                                 C, ldc, N, nm));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+void tn_shape(int No, int& nNb, int& T) {
+  const int t16 = cdiv_i(No, 16);
+  nNb = cdiv_i(t16, 14);
+  T = cdiv_i(cdiv_i(t16, nNb), 2);       // <= 7
+}
+
+template <int T16>
+int launch_tn_t(const float* A, int lda, const float* B, int ldb, int K, int splitk, float* P, int Mo, int No, int nNb,
+                hipStream_t st) {
+  const int ntiles = cdiv_i(Mo, T_BM) * nNb;
+  const int kchunk = cdiv_i(cdiv_i(K, splitk), T_BK) * T_BK;
+  const size_t smem = 2 * (size_t)T_BK * (T_BM + 16 + 32 * T16 + 16) * 4;
+  static std::atomic<unsigned long long> done{0};
+  if (ensure_dyn_smem((const void*)gemm32_tn_kernel<T16>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  static const std::string name = "gemm32_tn_kernel<" + std::to_string(T16) + ">";
+  const double fl = 2.0 * Mo * (double)No * K;
+  const double by = 4.0 * ((double)K * Mo + (double)K * No + (double)Mo * No * splitk);
+  const int grid = cdiv_i(splitk, 8) * 8 * ntiles;
+  PROF_LAUNCH(name.c_str(), fl, by, st,
+              hipLaunchKernelGGL(gemm32_tn_kernel<T16>, dim3(grid), dim3(64 * G_WAVES), smem, st, A, lda, B, ldb, K,
+                                 kchunk, splitk, P, Mo, No, nNb, ntiles));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+}  // namespace
+
+// Rows the padded B operand of an N-column product must have (whole workgroup tiles).
+int gemm32_nt_rows(int N) {
+  int nsl, T;
+  nt_shape(N, nsl, T);
+  return nsl * 64 * T;
+}
+
+// The big-tile kernels pay off once every CU has a 128-row tile of its own; they need the contraction padded to 32 and
+// short enough for a single fp32 accumulation chain (the general kernel folds every 512).
+bool gemm32_supported(size_t BT, int Kp_f, int Kp_b) {
+  return BT >= 24576 && Kp_f % 32 == 0 && Kp_b % 32 == 0 && Kp_f <= 512 && Kp_b <= 512;
+}
+
+int launch_pad_weight(const float* W, int R, int C, int transpose, const float* bias, float* out, int Ro, int Co,
+                      hipStream_t st) {
+  const size_t n = (size_t)Ro * Co;
+  PROF_LAUNCH("pad_weight_kernel", 0.0, 4.0 * (n + (double)R * C), st,
+              hipLaunchKernelGGL(pad_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, R, C,
+                                 transpose, bias, out, Ro, Co));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
+// C[M][N] = A[M][Kp] Bp[.][Kp]^T; A rows 16-byte aligned (lda % 4 == 0), Bp with gemm32_nt_rows(N) zero-padded rows.
+int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, hipStream_t st) {
+  int nsl, T;
+  nt_shape(N, nsl, T);
+  if (Kp % 32 != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bp & 15)) return WGNN_ERR_SHAPE;
+  switch (T) {
+#define NT_CASE(t) \
+  case t: return launch_nt_t<t>(A, lda, M, Kp, Bp, C, ldc, N, nsl, st);
+    NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5) NT_CASE(6) NT_CASE(7)
+#undef NT_CASE
+  }
+  return WGNN_ERR_SHAPE;
+}
+
+// Workgroup tiles of the split-K product (for the split-K choice) and the product itself:
+// P[z][Mo][No] = sum over K chunk z of A[k][m] B[k][n]; rows of A and B 16-byte aligned; reduce with launch_splitk_reduce.
+int gemm32_tn_tiles(int Mo, int No) {
+  int nNb, T;
+  tn_shape(No, nNb, T);
+  return cdiv_i(Mo, T_BM) * nNb;
+}
+int launch_gemm32_tn(const float* A, int lda, const float* B, int ldb, int K, int splitk, float* P, int Mo, int No,
+                     hipStream_t st) {
+  int nNb, T;
+  tn_shape(No, nNb, T);
+  if (lda % 4 != 0 || ldb % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || splitk < 1) return WGNN_ERR_SHAPE;
+  switch (T) {
+#define TN_CASE(t) \
+  case t: return launch_tn_t<t>(A, lda, B, ldb, K, splitk, P, Mo, No, nNb, st);
+    TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(7)
+#undef TN_CASE
+  }
+  return WGNN_ERR_SHAPE;
+}
+
+int launch_hprev_pad(const float* Y, int B, int T, int H, float* out, int ld, hipStream_t st) {
+  const size_t BT = (size_t)B * T, n = BT * ld;
+  if (ld % 4 != 0) return WGNN_ERR_SHAPE;
+  PROF_LAUNCH("hprev_pad_kernel", 0.0, 4.0 * (n + (double)BT * H), st,
+              hipLaunchKernelGGL(hprev_pad_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, Y, BT, T, H,
+                                 out, ld));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
