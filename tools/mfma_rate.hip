@@ -32,6 +32,18 @@ __global__ void __launch_bounds__(256) k(float* sink, int iters) {
     }
     a0 += a1 + a2 + a3;
     if (a0[0] == 12345.f) sink[threadIdx.x] = a0[1];
+  } else if (KIND == 3) {   // v_mfma_f32_32x32x16_f16: 32768 flop, 32 cycles at the dense peak
+    f16x8 h;
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)s;
+    f32x16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    for (int i = 0; i < iters; ++i) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, a3, 0, 0, 0);
+    }
+    a0 += a1 + a2 + a3;
+    if (a0[0] == 12345.f) sink[threadIdx.x] = a0[1];
   } else {                  // v_mfma_f32_16x16x32_f16: 16384 flop, 16 cycles at the dense peak
     f16x8 h;
     for (int j = 0; j < 8; ++j) h[j] = (_Float16)s;
@@ -67,10 +79,11 @@ static void run(float* d, const char* name, double flop, double cycles, int wgs_
 
 int main() {
   float* d; (void)hipMalloc(&d, 1 << 20);
-  for (int w = 1; w <= 2; ++w) {
+  for (int w = 1; w <= 4; ++w) {
     run<0>(d, "v_mfma_f32_32x32x2_f32", 4096, 64, w, 2000 / w);
     run<1>(d, "v_mfma_f32_16x16x4_f32", 2048, 32, w, 4000 / w);
     run<2>(d, "v_mfma_f32_16x16x32_f16", 16384, 16, w, 8000 / w);
+    run<3>(d, "v_mfma_f32_32x32x16_f16", 32768, 32, w, 4000 / w);
   }
   return 0;
 }

@@ -7,10 +7,11 @@
 //   TN  P[z][Mo][No]   = sum_k A[k][m] * B[k][n]        dW_ih = dGI^T [g|1], dW_hh = dGH^T [Hprev|1]
 //
 // Both kernels stage their operands with LDS-DMA (global_load_lds_dwordx4, swizzle applied on the
-// source address) into a two-stage ring and run ONE large workgroup per CU: these kernels sit at the
-// MFMA rate the chip sustains on real data (its clock drops to ~1.45 GHz under this load), and at
-// that clock the CU's L2 -> LDS path is the co-limiter, so tiles are as large as LDS allows to
-// minimise the bytes staged per MFMA.  All MFMAs are v_mfma_f32_16x16x32_f16.
+// source address) into a two-stage ring and run ONE large workgroup per CU: what bounds these kernels
+// is the CU's L2 -> LDS path (~17-23 B/clk measured; SQ counters: matrix pipe 33-39 % busy, waves half
+// their time waiting for the next stage), so tiles are as large as LDS and the register file allow to
+// minimise the bytes staged per MFMA.  All MFMAs are v_mfma_f32_16x16x32_f16 (a 32x32x16 rebuild of the
+// NT kernel measured 8 % slower: DESIGN.md section 5).
 #include <string>
 
 #include "common.h"
@@ -24,8 +25,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // NT.  One 12-wave workgroup per CU owns a 192 x 32T tile: waves 6 (M) x 2 (N), wave tile 32 x 16T
-// built from v_mfma_f32_16x16x32_f16 (K step = one 64-byte LDS row).  Under MFMA load the chip
-// clocks down (~1.45 GHz here) and with it the CU's load path, which is what bounds this kernel:
+// built from v_mfma_f32_16x16x32_f16 (K step = one 64-byte LDS row).  The CU's L2 -> LDS load path
+// is what bounds this kernel:
 // the tile is as tall and as wide as LDS allows so that the fewest bytes cross L2 -> LDS per MFMA
 // (A is staged once per M tile when N <= 320, B once per 192 rows).
 constexpr int NT_BM = 192, NT_WAVES = 12;
