@@ -273,9 +273,11 @@ def test_full_size_properties_B4096(math):
 
 @pytest.mark.parametrize("S,T,B,H", [(34, 24, 1100, 102), (7, 24, 1100, 21), (20, 30, 900, 64), (34, 24, 1500, 128)])
 def test_exact_fp32_big_tile_gemms(S, T, B, H):
-    """Exact-fp32 mode at B*T >= 24576 switches GI, dg and dW_ih to the big-tile LDS-DMA GEMMs (csrc/gemm32.hip); two
-    half batches stay on the general kernel (csrc/gemm.hip).  The two routes must agree to fp32 rounding (Y per window,
-    gradients summed over the halves), and the big route must agree with the fp64 oracle (first shape)."""
+    """Exact-fp32 mode at B*T >= 24576 runs GI / dg on the 128-row LDS-DMA GEMM tiles and dW_ih / dW_hh on the split-K
+    LDS-DMA kernel (csrc/gemm32.hip); two half batches take the 32-row NT form and the general split-K kernel
+    (csrc/gemm.hip).  The two routes must agree to fp32 rounding (Y per window, gradients summed over the halves), and
+    the big route must agree with the fp64 oracle (first shape).  (Below B*T = 4096 everything is the general kernel:
+    the golden-fixture tests; B = 256, T = 24 against the oracle covers the 32-row form.)"""
     from oracle import windgnn_oracle as orc
     from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
     dev = _dev()

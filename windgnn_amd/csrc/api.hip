@@ -19,7 +19,7 @@ struct Layout {
   int sk_ih, sk_hh;
   // which kernels run: the fp16-plane family needs the dense LDS-resident GCN and the register-resident GRU;
   // shapes beyond the fast kernels (CSR adjacency, wide hidden state) use general.hip in exact fp32
-  bool x3, gen_gcn, gen_gru, g32;
+  bool x3, gen_gcn, gen_gru, g32, g32tn;
   int hq;
   size_t ws_hprev;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
@@ -55,7 +55,8 @@ Layout make_layout(const wgnn_dims* d) {
   L.np_i = pgemm_nt_np((int)L.I);
   auto al = [](size_t x) { return align_up(x, 64); };
   // exact fp32 at large B*T: the big-tile GEMMs of gemm32.hip on zero-padded copies of W_ih / W_ih^T
-  L.g32 = !x3 && !L.gen_gcn && !L.gen_gru && gemm32_supported(L.BT, (int)L.Ip, (int)L.Gp);
+  L.g32 = !x3 && !L.gen_gcn && !L.gen_gru && gemm32_nt_supported(L.BT, (int)L.Ip, (int)L.Gp);
+  L.g32tn = L.g32 && gemm32_tn_supported(L.BT);          // the split-K dW products need more rows than GI / dg
   const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : (L.g32 ? (size_t)gemm32_nt_rows((int)L.G3) * L.Ip : 0);   // 2 planes of halfs = that many floats
   const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : (L.g32 ? (size_t)gemm32_nt_rows((int)L.I) * L.Gp : 0);
   constexpr size_t HDR = WGNN_STATUS_BYTES / sizeof(float);   // status block at the start of the workspace
@@ -91,9 +92,9 @@ Layout make_layout(const wgnn_dims* d) {
     L.sk_hh = pick_splitk(L.BT, pgemm_tn_tiles(L.m_hh, (int)L.H + 1), 256, 64);
   } else {
     // K chunks of at least 128 rows (B*T = 6144 at BASELINE configs[1]: with 256-row chunks the dW_hh product had 72 workgroups)
-    L.sk_ih = L.g32 ? pick_splitk(L.BT, gemm32_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64)   // one workgroup per CU
+    L.sk_ih = L.g32tn ? pick_splitk(L.BT, gemm32_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64)   // one workgroup per CU
                     : pick_splitk(L.BT, gemm_f32_tiles((int)L.G3, (int)L.I + 1), 1024, 128);
-    L.sk_hh = L.g32 ? pick_splitk(L.BT, gemm32_tn_tiles((int)L.G3, (int)L.H + 1), 256, 64)
+    L.sk_hh = L.g32tn ? pick_splitk(L.BT, gemm32_tn_tiles((int)L.G3, (int)L.H + 1), 256, 64)
                     : pick_splitk(L.BT, gemm_f32_tiles((int)L.G3, (int)L.H + 1), 1024, 128);
   }
   size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
@@ -113,7 +114,7 @@ Layout make_layout(const wgnn_dims* d) {
     L.ws_gcnpart = o; o += al(a > b ? a : b);
   }
   L.hq = (int)rup(L.H + 1, 16);
-  L.ws_hprev = o; o += al(L.g32 ? L.BT * (size_t)L.hq : 0);    // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
+  L.ws_hprev = o; o += al(L.g32tn ? L.BT * (size_t)L.hq : 0);    // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
   L.ws_du = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.ws_dhz = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
   L.ws_dhw = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
@@ -433,7 +434,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
   }
   if (do_wg) {
     // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
-    if (L.g32) {
+    if (L.g32tn) {
       float* hp = ws + L.ws_hprev;
       rc = launch_hprev_pad(Y, d->B, d->T, d->H, hp, L.hq, st);
       if (rc != WGNN_OK) return rc;
@@ -450,7 +451,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, nullptr, st);
     if (rc != WGNN_OK) return rc;
     // dW_ih = dGI^T g, db_ih = dGI^T 1
-    if (L.g32) {       // g carries its ones column (gcn32_fwd)
+    if (L.g32tn) {     // g carries its ones column (gcn32_fwd)
       rc = launch_gemm32_tn(dGI, (int)L.Gp, gact, (int)L.Ip, (int)L.BT, L.sk_ih, part, (int)L.G3, (int)L.I + 1, st);
     } else {
       GemmArgs b = {};

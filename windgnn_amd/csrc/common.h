@@ -97,7 +97,8 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st);
 void gemm_f32_tile(int M, int N, int* bm, int* bn);
 int gemm_f32_tiles(int M, int N);
 // gemm32.hip: big-tile exact-fp32 GEMMs for large B*T (operands padded and 16-byte aligned)
-bool gemm32_supported(size_t BT, int Kp_f, int Kp_b);
+bool gemm32_nt_supported(size_t BT, int Kp_f, int Kp_b);
+bool gemm32_tn_supported(size_t BT);
 int gemm32_nt_rows(int N);
 int launch_pad_weight(const float* W, int R, int C, int transpose, const float* bias, float* out, int Ro, int Co,
                       hipStream_t st);

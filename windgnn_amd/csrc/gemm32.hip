@@ -19,25 +19,27 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
 // ------------------------------------------------------------------------------------------------
-// NT.  8 waves = 4 (M) x 2 (N); wave tile 32 x 32 T32, workgroup tile 128 x 64 T32; K step 32 = one 128-byte LDS row.
+// NT.  MW (M) x NW (N) waves; wave tile 32 x 32 T32, workgroup tile 32 MW x 32 T32 NW; K step 32 = one 128-byte LDS row.
+// Two forms: 4 x 2 waves with T32 <= 7 (128-row tiles, one workgroup per CU: B*T >= 24576) and 1 x NW waves with
+// T32 = 1 (32-row tiles, one wave per 32 output columns: a few thousand rows still give most CUs a workgroup).
 // A k group of 8 = two 16-byte chunks: lane (i, kh) of the 32x32x2 MFMA reads chunk 2 kk + kh of row i as ONE
 // ds_read_b128; its element jj is the operand of MFMA jj, whose two k slots are therefore k = 8 kk + jj and 8 kk + 4 + jj
 // -- any bijection works as long as A and B agree.  The 16-byte chunks of a row are XOR-swizzled by (row >> 1) & 7
 // (applied on the DMA source address), which makes the 16 rows x 16 B of a quarter-wave hit 16 different bank groups.
-constexpr int G_BM = 128, G_WAVES = 8;
+constexpr int G_WAVES = 8;      // the TN kernel's and the big NT form's
 
-template <int T32>
-__global__ void __launch_bounds__(64 * G_WAVES) gemm32_nt_kernel(const float* __restrict__ A, int lda, int M, int Kp,
+template <int MW, int NW, int T32>
+__global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __restrict__ A, int lda, int M, int Kp,
                                                                const float* __restrict__ Bp, float* __restrict__ C,
                                                                int ldc, int N, int nm) {
-  constexpr int BN = 64 * T32;
+  constexpr int G_BM = 32 * MW, BN = 32 * T32 * NW, NWAVES = MW * NW;
   constexpr int A_BYTES = G_BM * 128, STAGE = A_BYTES + BN * 128;
   constexpr int AP = G_BM / 8, BP = BN / 8;                      // 1 KB pieces: 8 rows x 128 B
-  constexpr int NPIECE = AP + BP, NIT = (NPIECE + G_WAVES - 1) / G_WAVES;
+  constexpr int NPIECE = AP + BP, NIT = (NPIECE + NWAVES - 1) / NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % MW, wn = wave / MW;
   const int mt = blockIdx.x % nm, sl = blockIdx.x / nm;
   const int m0 = mt * G_BM, n0 = sl * BN;
 
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(64 * G_WAVES) gemm32_nt_kernel(const float* __
     const int r8 = lane >> 3, pos = lane & 7;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int p = wave + G_WAVES * it;
+      const int p = wave + NWAVES * it;
       on[it] = p < NPIECE;                                        // wave-uniform
       const int pp = on[it] ? p : 0;
       const bool isA = pp < AP;
@@ -253,25 +255,29 @@ __global__ void hprev_pad_kernel(const float* __restrict__ Y, size_t BT, int T, 
   *(f32x4*)(out + bt * ld + c) = v;
 }
 
-void nt_shape(int N, int& nsl, int& T) {
+// big form: N slices of 64 T32 columns (T32 <= 7: 2 x 56 KB of B + 2 x 16 KB of A fill the CU's LDS);
+// small form: N slices of 32 NW columns (NW <= 14 waves)
+void nt_shape(int N, bool big, int& nsl, int& T) {
   const int t32 = cdiv_i(N, 32);
   nsl = cdiv_i(t32, 14);
-  T = cdiv_i(cdiv_i(t32, nsl), 2);       // <= 7: 2 x 56 KB of B + 2 x 16 KB of A fill the CU's LDS
+  T = big ? cdiv_i(cdiv_i(t32, nsl), 2) : cdiv_i(t32, nsl);
 }
+// 128-row tiles once they give most CUs a workgroup of their own, 32-row tiles below that
+bool nt_big(int M) { return cdiv_i(M, 128) >= 192; }
 
-template <int T32>
+template <int MW, int NW, int T32>
 int launch_nt_t(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, int nsl,
                 hipStream_t st) {
-  const int nm = cdiv_i(M, G_BM);
-  const size_t smem = 2 * (size_t)(G_BM + 64 * T32) * 128;
+  const int nm = cdiv_i(M, 32 * MW);
+  const size_t smem = 2 * (size_t)(32 * MW + 32 * T32 * NW) * 128;
   static std::atomic<unsigned long long> done{0};
-  if (ensure_dyn_smem((const void*)gemm32_nt_kernel<T32>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  static const std::string name = "gemm32_nt_kernel<" + std::to_string(T32) + ">";
+  if (ensure_dyn_smem((const void*)gemm32_nt_kernel<MW, NW, T32>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  static const std::string name = "gemm32_nt_kernel<" + std::to_string(32 * MW) + "x" + std::to_string(32 * T32 * NW) + ">";
   const double fl = 2.0 * M * (double)N * Kp;
   const double by = 4.0 * ((double)M * Kp + (double)N * Kp + (double)M * N);
   PROF_LAUNCH(name.c_str(), fl, by, st,
-              hipLaunchKernelGGL(gemm32_nt_kernel<T32>, dim3(nm * nsl), dim3(64 * G_WAVES), smem, st, A, lda, M, Kp, Bp,
-                                 C, ldc, N, nm));
+              hipLaunchKernelGGL((gemm32_nt_kernel<MW, NW, T32>), dim3(nm * nsl), dim3(64 * MW * NW), smem, st, A, lda,
+                                 M, Kp, Bp, C, ldc, N, nm));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -303,18 +309,22 @@ int launch_tn_t(const float* A, int lda, const float* B, int ldb, int K, int spl
 
 }  // namespace
 
-// Rows the padded B operand of an N-column product must have (whole workgroup tiles).
+// Rows the padded B operand of an N-column product must have (whole workgroup tiles of either form).
 int gemm32_nt_rows(int N) {
-  int nsl, T;
-  nt_shape(N, nsl, T);
-  return nsl * 64 * T;
+  int nsl, T, nsl2, T2;
+  nt_shape(N, true, nsl, T);
+  nt_shape(N, false, nsl2, T2);
+  const int a = nsl * 64 * T, b = nsl2 * 32 * T2;
+  return a > b ? a : b;
 }
 
-// The big-tile kernels pay off once every CU has a 128-row tile of its own; they need the contraction padded to 32 and
-// short enough for a single fp32 accumulation chain (the general kernel folds every 512).
-bool gemm32_supported(size_t BT, int Kp_f, int Kp_b) {
-  return BT >= 24576 && Kp_f % 32 == 0 && Kp_b % 32 == 0 && Kp_f <= 512 && Kp_b <= 512;
+// The LDS-DMA kernels need the contraction padded to 32 and short enough for a single fp32 accumulation chain (the
+// general kernel folds every 512).  NT pays off from a few thousand rows (32-row tiles), the split-K TN form once every
+// CU has a K chunk of several stages.
+bool gemm32_nt_supported(size_t BT, int Kp_f, int Kp_b) {
+  return BT >= 4096 && Kp_f % 32 == 0 && Kp_b % 32 == 0 && Kp_f <= 512 && Kp_b <= 512;
 }
+bool gemm32_tn_supported(size_t BT) { return BT >= 24576; }
 
 int launch_pad_weight(const float* W, int R, int C, int transpose, const float* bias, float* out, int Ro, int Co,
                       hipStream_t st) {
@@ -328,13 +338,24 @@ int launch_pad_weight(const float* W, int R, int C, int transpose, const float* 
 
 // C[M][N] = A[M][Kp] Bp[.][Kp]^T; A rows 16-byte aligned (lda % 4 == 0), Bp with gemm32_nt_rows(N) zero-padded rows.
 int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, hipStream_t st) {
+  const bool big = nt_big(M);
   int nsl, T;
-  nt_shape(N, nsl, T);
+  nt_shape(N, big, nsl, T);
   if (Kp % 32 != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bp & 15)) return WGNN_ERR_SHAPE;
+  if (big) {
+    switch (T) {
+#define NT_CASE(t) \
+  case t: return launch_nt_t<4, 2, t>(A, lda, M, Kp, Bp, C, ldc, N, nsl, st);
+      NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5) NT_CASE(6) NT_CASE(7)
+#undef NT_CASE
+    }
+    return WGNN_ERR_SHAPE;
+  }
   switch (T) {
 #define NT_CASE(t) \
-  case t: return launch_nt_t<t>(A, lda, M, Kp, Bp, C, ldc, N, nsl, st);
-    NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5) NT_CASE(6) NT_CASE(7)
+  case t: return launch_nt_t<1, t, 1>(A, lda, M, Kp, Bp, C, ldc, N, nsl, st);
+    NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5) NT_CASE(6) NT_CASE(7) NT_CASE(8) NT_CASE(9) NT_CASE(10)
+    NT_CASE(11) NT_CASE(12) NT_CASE(13) NT_CASE(14)
 #undef NT_CASE
   }
   return WGNN_ERR_SHAPE;
