@@ -19,6 +19,7 @@
 #include "common.h"
 
 namespace {
+#define LIVE(i, r) ((i) < NT - 1 || (r) < rl)
 
 constexpr int F13 = 13;
 constexpr int FP = 16;
@@ -80,6 +81,8 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcn32_fwd_kernel(int ntiles, i
   __shared__ __attribute__((aligned(16))) float sbuf[FWD_WAVES * 2 * SP * XS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int I = S * F13;
+  // MFMA (i, r) of a contraction over stations covers s = 16 i + r + 4 g: in the last row tile the r >= rl ones hold padding only
+  const int rl = S - 16 * (NT - 1);
   float* xb = sbuf + wave * 2 * SP * XS;
   float* ob = xb + SP * XS;
   for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;   // pads (f >= 13, s >= S) stay zero forever
@@ -143,7 +146,8 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcn32_fwd_kernel(int ntiles, i
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16(U[i][r], CT[n][i][r], acc);
+        for (int r = 0; r < 4; ++r)
+          if (LIVE(i, r)) acc = mfma16(U[i][r], CT[n][i][r], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) Ht[n][r] = fmaxf(acc[r] + bb1[r], 0.f);
     }
@@ -160,7 +164,8 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcn32_fwd_kernel(int ntiles, i
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16(U[i][r], CT[n][i][r], acc);
+        for (int r = 0; r < 4; ++r)
+          if (LIVE(i, r)) acc = mfma16(U[i][r], CT[n][i][r], acc);
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bb2[r], 0.f);
@@ -214,6 +219,8 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
   static_assert(2 * SP * XS >= PART, "the per-wave staging buffer doubles as its reduction row");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int I = S * F13;
+  // MFMA (i, r) of a contraction over stations covers s = 16 i + r + 4 g: in the last row tile the r >= rl ones hold padding only
+  const int rl = S - 16 * (NT - 1);
   float* xb = sbuf + wave * 2 * SP * XS;
   float* db = xb + SP * XS;
   for (int i = lane; i < 2 * SP * XS; i += 64) xb[i] = 0.f;
@@ -285,7 +292,8 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16(ldA(mi, i, r), U[i][r], acc);
+        for (int r = 0; r < 4; ++r)
+          if (LIVE(i, r)) acc = mfma16(ldA(mi, i, r), U[i][r], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s = 16 * mi + 4 * g + r;
@@ -310,13 +318,15 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16(ldT(mi, i, r), dZ[i][r], acc);
+        for (int r = 0; r < 4; ++r)
+          if (LIVE(i, r)) acc = mfma16(ldT(mi, i, r), dZ[i][r], acc);
       dU[mi] = acc;
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dW2acc = mfma16(H1[i][r], dU[i][r], dW2acc);
+      for (int r = 0; r < 4; ++r)
+        if (LIVE(i, r)) dW2acc = mfma16(H1[i][r], dU[i][r], dW2acc);
     // ---- dH1 [s'][f] = dU2 W2^T: through the wave's tile (dZ2 in it has been consumed)
     wave_lds_fence();
 #pragma unroll
@@ -344,13 +354,15 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = mfma16(ldT(mi, i, r), dZ[i][r], acc);
+        for (int r = 0; r < 4; ++r)
+          if (LIVE(i, r)) acc = mfma16(ldT(mi, i, r), dZ[i][r], acc);
       dU[mi] = acc;
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dW1acc = mfma16(xb[(16 * i + 4 * g + r) * XS + c], dU[i][r], dW1acc);
+      for (int r = 0; r < 4; ++r)
+        if (LIVE(i, r)) dW1acc = mfma16(xb[(16 * i + 4 * g + r) * XS + c], dU[i][r], dW1acc);
   }
 
   // ---- per-block reduction, one partial row per block (deterministic order)
