@@ -33,6 +33,18 @@ struct Frag { h8 hi, lo; };
 __device__ __forceinline__ f32x4 mfma_x(h8 a, h8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x16_f16 on the first four k slots (j < 4) of two fragments: half the matrix-pipe time of the K = 32
+// form.  Used wherever the slots j >= 4 are padding: every product over the 13 -> 16 features, and the last k step of a
+// product over stations when the number of 16-row tiles is odd (S = 34: stations 32..47 of 32..63).
+// MIXED_FORMS: the two forms never feed one accumulator -- a product that has steps of both kinds keeps one accumulator
+// per form and adds them on the VALU.  hipcc (ROCm 7.2) does not insert the wait states between a v_mfma_f32_16x16x32_f16
+// and a v_mfma_f32_16x16x16_f16 of which one takes the other's result as SrcC: a two-MFMA test kernel read a stale
+// accumulator (right again with any instruction in between), and so did these kernels in either order of the steps.
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_h(h8 a, h8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(a, a, 0, 1, 2, 3),
+                                               __builtin_shufflevector(b, b, 0, 1, 2, 3), c, 0, 0, 0);
+}
 // X3 = true: split-fp16 product lo*hi + hi*lo + hi*hi (fp32-grade); X3 = false: plain fp16 operands, one pass
 // (the "f16" math mode for BASELINE's 16-bit configuration; lo halves are never formed).
 template <bool X3>
@@ -42,6 +54,15 @@ __device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
     c = mfma_x(a.hi, b.lo, c);
   }
   c = mfma_x(a.hi, b.hi, c);
+  return c;
+}
+template <bool X3>
+__device__ __forceinline__ f32x4 mfma3h(const Frag& a, const Frag& b, f32x4 c) {
+  if (X3) {
+    c = mfma_h(a.lo, b.hi, c);
+    c = mfma_h(a.hi, b.lo, c);
+  }
+  c = mfma_h(a.hi, b.hi, c);
   return c;
 }
 // hi = fp16(x) (v_cvt_pk_f16_f32, 2 values per instruction), lo = fp16(x - hi) with the difference
@@ -91,6 +112,24 @@ template <bool X3>
 __device__ __forceinline__ Frag frag_of(f32x4 t0, f32x4 t1) {
   const float x[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
   return split_vals<X3>(x);
+}
+// half fragment: slots j < 4 from one accumulator row-tile (or four values), slots j >= 4 unused (mfma3h)
+template <bool X3>
+__device__ __forceinline__ Frag frag_half(f32x4 t) {
+  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    unsigned h, l = 0u;
+    if (X3) split2(t[2 * j], t[2 * j + 1], h, l);
+    else h = cvt2(t[2 * j], t[2 * j + 1]);
+    hi[j] = h;
+    lo[j] = l;
+  }
+  Frag f;
+  f.hi = __builtin_bit_cast(h8, hi);
+  f.lo = __builtin_bit_cast(h8, lo);
+  return f;
 }
 // max(z, 0) for finite z; NaN for z = NaN or +-inf (0 * z is +-0 or NaN): one v_fma more than the plain ReLU
 __device__ __forceinline__ float relu_nan(float z) { return __builtin_fmaf(z, 0.f, fmaxf(z, 0.f)); }
@@ -200,15 +239,10 @@ __device__ __forceinline__ void gload_pairs_h(h2 (&r)[NP], const _Float16* __res
   }
 }
 
-// A-operand fragment (natural k = f) of X rows 16i + c from the staged tile
+// A-operand half fragment (k = f = 4g + j, j < 4) of rows 16i + c of a staged [s][XS] tile
 template <bool X3>
 __device__ __forceinline__ Frag xfrag_nat(const float* xb, int i, int c, int g) {
-  const f32x4 v0 = *(const f32x4*)(xb + (16 * i + c) * XS + 8 * (g & 1));
-  const f32x4 v1 = *(const f32x4*)(xb + (16 * i + c) * XS + 8 * (g & 1) + 4);
-  // lane groups g >= 2 (k = 8g + j >= 16) hold a second copy of the same finite data: every B operand this fragment
-  // meets (W1, W2^T) is zero for k >= 13, so no select is needed to zero them
-  const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-  return split_vals<X3>(x);
+  return frag_half<X3>(*(const f32x4*)(xb + (16 * i + c) * XS + 4 * g));
 }
 
 constexpr int FWD_WAVES = 8;   // waves per forward block (A fragments are shared through LDS)
@@ -262,9 +296,8 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
     float x1[8], x2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int f = 8 * g + j;                       // natural k = f for X W1
-      x1[j] = (f < F13 && c < F13) ? W1[f * F13 + c] : 0.f;
-      const int f2 = 4 * g + j;                      // rho order over one 16-row tile for H1 W2
+      const int f2 = 4 * g + j;                      // k = f = 4g + j, j < 4 (half fragments)
+      x1[j] = (j < 4 && f2 < F13 && c < F13) ? W1[f2 * F13 + c] : 0.f;
       x2[j] = (j < 4 && f2 < F13 && c < F13) ? W2[f2 * F13 + c] : 0.f;
     }
     FW1 = split_vals<X3>(x1);
@@ -306,30 +339,40 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 
     f32x4 U[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) U[i] = mfma3<X3>(xfrag_nat<X3>(xb, i, c, g), FW1, zero4);   // U1 row-tile i
+    for (int i = 0; i < NT; ++i) U[i] = mfma3h<X3>(xfrag_nat<X3>(xb, i, c, g), FW1, zero4);   // U1 row-tile i
     Frag UF[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of<X3>(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = (2 * ks + 1 < NT) ? frag_of<X3>(U[2 * ks], U[2 * ks + 1]) : frag_half<X3>(U[2 * ks]);
     f32x4 Ht[NT];                                    // H1^T column-tile n: [f][s = 16n + c]
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       f32x4 acc = zero4;
+      f32x4 acc16 = zero4;                       // the K = 16 step has its own accumulator (MIXED_FORMS)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (2 * ks + 1 < NT) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
+        else acc16 = mfma3h<X3>(UF[ks], ldA(n, ks), acc16);
+      }
+      if (NT & 1) acc += acc16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         Ht[n][r] = relu_nan(acc[r] + bb1[r]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) U[i] = mfma3<X3>(frag_of<X3>(Ht[i], zero4), FW2, zero4);   // U2 row-tile i [s][f']
+    for (int i = 0; i < NT; ++i) U[i] = mfma3h<X3>(frag_half<X3>(Ht[i]), FW2, zero4);   // U2 row-tile i [s][f']
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of<X3>(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = (2 * ks + 1 < NT) ? frag_of<X3>(U[2 * ks], U[2 * ks + 1]) : frag_half<X3>(U[2 * ks]);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       f32x4 acc = zero4;
+      f32x4 acc16 = zero4;                       // the K = 16 step has its own accumulator (MIXED_FORMS)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (2 * ks + 1 < NT) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
+        else acc16 = mfma3h<X3>(UF[ks], ldA(n, ks), acc16);
+      }
+      if (NT & 1) acc += acc16;
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -443,9 +486,9 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
     float x1[8], x2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int f = 8 * g + j;
-      x1[j] = (f < F13 && c < F13) ? W1[f * F13 + c] : 0.f;
-      x2[j] = (f < F13 && c < F13) ? W2[c * F13 + f] : 0.f;   // k = f' natural, n = c = f: W2^T[f'][f]
+      const int f = 4 * g + j;                       // k = 4g + j, j < 4 (half fragments)
+      x1[j] = (j < 4 && f < F13 && c < F13) ? W1[f * F13 + c] : 0.f;
+      x2[j] = (j < 4 && f < F13 && c < F13) ? W2[c * F13 + f] : 0.f;   // k = f', n = c = f: W2^T[f'][f]
     }
     FW1 = split_vals<X3>(x1);
     FW2T = split_vals<X3>(x2);
@@ -459,7 +502,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
   const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
 
-  f32x4 dW1acc = zero4, dW2acc = zero4;
+  f32x4 dW1acc = zero4, dW2acc = zero4, dW1acc16 = zero4, dW2acc16 = zero4;   // K = 32 / K = 16 steps (MIXED_FORMS)
   float db1acc = 0.f, db2acc = 0.f;
 
   f32x2 xr[NP], dr[NP];
@@ -492,16 +535,21 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
     // ---- recompute U1, H1 [s][f]
     f32x4 U[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) U[i] = mfma3<X3>(xfrag_nat<X3>(xb, i, c, g), FW1, zero4);
+    for (int i = 0; i < NT; ++i) U[i] = mfma3h<X3>(xfrag_nat<X3>(xb, i, c, g), FW1, zero4);
     Frag UF[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) UF[ks] = frag_of<X3>(U[2 * ks], (2 * ks + 1 < NT) ? U[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) UF[ks] = (2 * ks + 1 < NT) ? frag_of<X3>(U[2 * ks], U[2 * ks + 1]) : frag_half<X3>(U[2 * ks]);
     f32x4 H1[NT];
 #pragma unroll
     for (int mi = 0; mi < NT; ++mi) {
       f32x4 acc = zero4;
+      f32x4 acc16 = zero4;                       // the K = 16 step has its own accumulator (MIXED_FORMS)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(ldA(mi, ks), UF[ks], acc);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (2 * ks + 1 < NT) acc = mfma3<X3>(ldA(mi, ks), UF[ks], acc);
+        else acc16 = mfma3h<X3>(ldA(mi, ks), UF[ks], acc16);
+      }
+      if (NT & 1) acc += acc16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s = 16 * mi + 4 * g + r;
@@ -520,21 +568,27 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
       }
     Frag DZF[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) DZF[ks] = frag_of<X3>(dZ[2 * ks], (2 * ks + 1 < NT) ? dZ[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) DZF[ks] = (2 * ks + 1 < NT) ? frag_of<X3>(dZ[2 * ks], dZ[2 * ks + 1]) : frag_half<X3>(dZ[2 * ks]);
     // ---- dU2 [s'][f'] = A^T dZ2 ; dW2 += H1^T dU2
     f32x4 dU[NT];
 #pragma unroll
     for (int mi = 0; mi < NT; ++mi) {
       f32x4 acc = zero4;
+      f32x4 acc16 = zero4;                       // the K = 16 step has its own accumulator (MIXED_FORMS)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(ldT(mi, ks), DZF[ks], acc);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (2 * ks + 1 < NT) acc = mfma3<X3>(ldT(mi, ks), DZF[ks], acc);
+        else acc16 = mfma3h<X3>(ldT(mi, ks), DZF[ks], acc16);
+      }
+      if (NT & 1) acc += acc16;
       dU[mi] = acc;
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const f32x4 h1 = (2 * ks + 1 < NT) ? H1[2 * ks + 1] : zero4;
-      const f32x4 d1 = (2 * ks + 1 < NT) ? dU[2 * ks + 1] : zero4;
-      dW2acc = mfma3<X3>(frag_of<X3>(H1[2 * ks], h1), frag_of<X3>(dU[2 * ks], d1), dW2acc);
+      if (2 * ks + 1 < NT)
+        dW2acc = mfma3<X3>(frag_of<X3>(H1[2 * ks], H1[2 * ks + 1]), frag_of<X3>(dU[2 * ks], dU[2 * ks + 1]), dW2acc);
+      else
+        dW2acc16 = mfma3h<X3>(frag_half<X3>(H1[2 * ks]), frag_half<X3>(dU[2 * ks]), dW2acc16);
     }
     // ---- dH1 [s'][f] = dU2 W2^T contracts over dU2's COLUMN index: dU2 goes through the wave's staging buffer
     // (the dZ2 tile in it has been consumed) and comes back as natural-k A fragments -- 12 ds_write_b32 + 6
@@ -547,7 +601,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
     wave_lds_fence();
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const f32x4 dh = mfma3<X3>(xfrag_nat<X3>(db, n, c, g), FW2T, zero4);
+      const f32x4 dh = mfma3h<X3>(xfrag_nat<X3>(db, n, c, g), FW2T, zero4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = H1[n][r] > 0.f ? dh[r] : 0.f;
@@ -556,13 +610,18 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
       }
     }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) DZF[ks] = frag_of<X3>(dZ[2 * ks], (2 * ks + 1 < NT) ? dZ[2 * ks + 1] : zero4);
+    for (int ks = 0; ks < KS; ++ks) DZF[ks] = (2 * ks + 1 < NT) ? frag_of<X3>(dZ[2 * ks], dZ[2 * ks + 1]) : frag_half<X3>(dZ[2 * ks]);
     // ---- dU1 = A^T dZ1 ; dW1 += X^T dU1 (X read from the staged tile in C layout [s'][f])
 #pragma unroll
     for (int mi = 0; mi < NT; ++mi) {
       f32x4 acc = zero4;
+      f32x4 acc16 = zero4;                       // the K = 16 step has its own accumulator (MIXED_FORMS)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mfma3<X3>(ldT(mi, ks), DZF[ks], acc);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (2 * ks + 1 < NT) acc = mfma3<X3>(ldT(mi, ks), DZF[ks], acc);
+        else acc16 = mfma3h<X3>(ldT(mi, ks), DZF[ks], acc16);
+      }
+      if (NT & 1) acc += acc16;
       dU[mi] = acc;
     }
     f32x4 XC[NT];
@@ -572,9 +631,10 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
       for (int r = 0; r < 4; ++r) XC[i][r] = xb[(16 * i + 4 * g + r) * XS + c];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const f32x4 x1 = (2 * ks + 1 < NT) ? XC[2 * ks + 1] : zero4;
-      const f32x4 d1 = (2 * ks + 1 < NT) ? dU[2 * ks + 1] : zero4;
-      dW1acc = mfma3<X3>(frag_of<X3>(XC[2 * ks], x1), frag_of<X3>(dU[2 * ks], d1), dW1acc);
+      if (2 * ks + 1 < NT)
+        dW1acc = mfma3<X3>(frag_of<X3>(XC[2 * ks], XC[2 * ks + 1]), frag_of<X3>(dU[2 * ks], dU[2 * ks + 1]), dW1acc);
+      else
+        dW1acc16 = mfma3h<X3>(frag_half<X3>(XC[2 * ks]), frag_half<X3>(dU[2 * ks]), dW1acc16);
     }
   }
 
@@ -586,8 +646,8 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    mine[(4 * g + r) * FP + c] = dW1acc[r] * s_out;
-    mine[FP * FP + (4 * g + r) * FP + c] = dW2acc[r] * s_out;
+    mine[(4 * g + r) * FP + c] = (dW1acc[r] + dW1acc16[r]) * s_out;
+    mine[FP * FP + (4 * g + r) * FP + c] = (dW2acc[r] + dW2acc16[r]) * s_out;
   }
   // column sums: lanes c, c+16, c+32, c+48 hold partial sums of column c
   db1acc += __shfl_xor(db1acc, 16, 64);
