@@ -153,7 +153,7 @@ int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const fl
                      float* db2, float* partial, hipStream_t st);
 // register-chained split-fp16 variants (gcnx.hip)
 size_t gcnx2_bwd_partial_floats(int ntiles);
-int gcnx_bwd_grid(int ntiles, int S);
+int gcnx_bwd_grid(int ntiles, int S, bool x3);
 // g_planes: fp16 hi plane [ntiles][ldg] followed by the lo plane; column S*13 holds 1.0, later columns 0
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io /*wgnn_io of X*/, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, hipStream_t st);

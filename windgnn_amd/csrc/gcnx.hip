@@ -423,10 +423,12 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 // scales[1] at the end.
 // 12 waves per backward block, one block per CU: the chain of small dependent products is latency-bound, and
 // three waves per SIMD (166 VGPRs) hide more of it than two (measured 181 vs 198 us; 4-wave blocks, 2 per CU).
-constexpr int bwd_waves(int NT) { return 12; }   // (16 waves at 128 VGPRs spill: 291 vs 181 us)
+// One-pass fp16 (no lo halves) fits 128 VGPRs: 16 waves, four per SIMD (122 vs 129 us).  f16x3 at 128 VGPRs spills 17
+// registers (268 vs 136 us) and stays at 12 waves.
+constexpr int bwd_waves(int NT, bool X3) { return (!X3 && NT <= 3) ? 16 : 12; }
 
 template <int NT, bool X3, bool IO>
-__global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
+__global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const void* __restrict__ X, int io, const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const _Float16* __restrict__ gact, int ld_g,
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
   __shared__ __attribute__((aligned(16))) h8 sCA[2 * NF * 64];   // [frag][hi|lo][lane]
   __shared__ __attribute__((aligned(16))) h8 sCT[2 * NF * 64];
-  constexpr int BWD_WAVES = bwd_waves(NT);
+  constexpr int BWD_WAVES = bwd_waves(NT, X3);
   __shared__ __attribute__((aligned(16))) float sbuf[BWD_WAVES * 2 * SP * XS];
   static_assert(2 * SP * XS >= PART, "the per-wave staging buffer doubles as its reduction row");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -668,8 +670,8 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT)) gcnx_bwd_kernel(int ntiles
   }
 }
 
-int grid_x(int ntiles, int S) {
-  int g = cdiv_i(ntiles, bwd_waves((S + 15) / 16));
+int grid_x(int ntiles, int S, bool x3) {
+  int g = cdiv_i(ntiles, bwd_waves((S + 15) / 16, x3));
   const int cap = 256;                              // one block per CU, persistent over the tiles
   return g < 1 ? 1 : (g > cap ? cap : g);
 }
@@ -677,7 +679,7 @@ int grid_x(int ntiles, int S) {
 }  // namespace
 
 size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)256 * PART; }
-int gcnx_bwd_grid(int ntiles, int S) { return grid_x(ntiles, S); }
+int gcnx_bwd_grid(int ntiles, int S, bool x3) { return grid_x(ntiles, S, x3); }
 
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status,
@@ -718,10 +720,10 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   // what the launch reads: X and dg as fp32, and the fp16 hi plane of g (2 bytes x ldg per tile) as the ReLU mask
   const double by = (double)ntiles * (S * 13 * (io ? 2.0 : 4.0) + S * 13 * 4.0 + ldg * 2.0);
-  const dim3 grid(grid_x(ntiles, S));
+  const dim3 grid(grid_x(ntiles, S, x3));
 #define BWD_LAUNCH(NT, X3V, IOV, NAME)                                                                            \
   PROF_LAUNCH(NAME, fl, by, st,                                                                                   \
-              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV>), grid, dim3(64 * bwd_waves(NT)), 0, st, ntiles, S, A, X, io, \
+              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV>), grid, dim3(64 * bwd_waves(NT, X3V)), 0, st, ntiles, S, A, X, io, \
                                  W1, b1, W2, g, ldg, dg, scales, scale_in, partial))
 #define BWD_CASE(NT)                                                                                              \
   if (x3 && !io) BWD_LAUNCH(NT, true, false, "gcnx_bwd_kernel<" #NT ">");                                         \
