@@ -313,6 +313,36 @@ def test_exact_fp32_big_tile_gemms(S, T, B, H):
             assert rel_to_max(gk.cpu(), go[k]) <= 1e-5, k
 
 
+@pytest.mark.parametrize("S,T,B,H", [(5, 30, 140, 10), (20, 24, 200, 40), (34, 24, 180, 102), (13, 24, 300, 128)])
+def test_exact_fp32_32row_gemms_against_oracle(S, T, B, H):
+    """4096 <= B*T < 24576 in exact fp32: GI and dg run on the 32-row form of the LDS-DMA NT kernel (csrc/gemm32.hip:
+    one wave per 32 output columns, 1..14 waves), the dW products on the general split-K kernel.  Whole batch against
+    the fp64 oracle at the fp32 tolerance (several widths: 3H = 30..384 and S*13 = 65..442 output columns).
+    (Input seed: with seed 17 one layer-1 pre-activation of the S = 13 case is -7e-9 in fp64 and +1e-8 in fp32, a ReLU
+    tie that moves conv1's gradient by one term, 7e-4 of max; with 31 none of the four cases has |z| < 5e-7.)"""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
+    dev = _dev()
+    assert 4096 <= B * T < 24576
+    g = torch.Generator().manual_seed(31)
+    A = torch.rand(S, S, generator=g) / S
+    X = torch.rand(B, T, S, 13, generator=g)
+    dY = (torch.rand(B, T, H, generator=g) - 0.5) * 1e-3
+    p = orc.init_params(S, 13, H, seed=23)
+    model = _model_from(p, S, H, "f32")
+    params = [q.detach() for q in model.hot_path_parameters()]
+    Ad, Xd, dYd = A.to(dev), X.to(dev), dY.to(dev)
+    Y, stash, d = gcn_gru_forward_raw(Ad, Xd, params, model.math, want_stash=True)
+    grads = [torch.empty_like(q) for q in params]
+    gcn_gru_backward_raw(d, Ad, Xd, params, Y, dYd, stash, grads)
+    p64 = {k: v.double() for k, v in p.items()}
+    Yo, cache = orc.forward(A.double(), X.double(), p64)
+    go = orc.backward(A.double(), X.double(), p64, Yo, cache, dY.double())
+    assert max_abs(Y.cpu(), Yo) <= 1e-5
+    for k, gk in zip(PARAM_KEYS, grads):
+        assert rel_to_max(gk.cpu(), go[k]) <= 1e-5, k
+
+
 def test_backward_in_two_parts_equals_one_call():
     """wgnn_bwd_part(1) then (2) must give bit-identical gradients to wgnn_bwd (the data-parallel overlap path)."""
     from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
