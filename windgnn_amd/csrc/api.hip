@@ -11,7 +11,7 @@ struct Layout {
   size_t BT, I, Ip, G3, Gp, H, Hp;
   int np_g3, np_i;                 // padded plane rows of the two split-weight images (f16x3)
   // forward workspace (float offsets)
-  size_t ws_GI, ws_g, ws_planes_f, ws_Ylast, fwd_floats;
+  size_t ws_GI, ws_g, ws_planes_f, ws_Ylast, ws_xtail_f, ws_xtail_b, fwd_floats;
   // stash
   size_t st_g, st_gates, st_yp, stash_floats;
   // backward workspace
@@ -71,6 +71,7 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_hhp_f = o; o += al(L.gen_gru && x3 ? (size_t)L.np_g3 * L.Hp : 0);    // split(W_hh | b_hh)
   L.ws_kp_f = o; o += al(L.gen_gru && x3 ? pgemm_nt_kpart_floats(d->B, (int)L.Gp, (int)L.Hp) : 0);
   L.ws_hc = o; o += al(L.gen_gru && x3 ? (size_t)d->B * L.Hp : 0);          // compact planes of h_{t-1}
+  L.ws_xtail_f = o; o += al((L.I & 1) && !L.gen_gcn ? L.I + 1 : 0);        // private copy of X's last tile (odd S*13: see xtail_copy)
   L.ws_Ylast = o; o += al((x3 && !L.gen_gru) ? 0 : L.BT * L.H);             // wgnn_fwd_last where the recurrence writes all of Y
   L.fwd_floats = o;
   o = 0;
@@ -124,6 +125,7 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_planes_b = o; o += al(planes_b);
   L.ws_scales = o; o += al(4096);          // 3 scales, then up to 2 x 1024 block partials from offset 64
   L.ws_dY = o; o += al(L.BT * L.H);          // wgnn_bwd_mse_part outside the fused kernel: dY lives here
+  L.ws_xtail_b = o; o += al((L.I & 1) && !L.gen_gcn ? L.I + 1 : 0);
   L.bwd_floats = o;
   return L;
 }
@@ -222,7 +224,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
                                status, st);
     else
       rc = launch_gcnx2_fwd((int)L.BT, d->S, A, X, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight,
-                            p->conv2_bias, g, (int)L.Ip, full, status, st);
+                            p->conv2_bias, g, (int)L.Ip, full, status, ws + L.ws_xtail_f, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
@@ -251,7 +253,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
                              p->conv2_weight, p->conv2_bias, h1, g, nullptr, L.Ip, false, nullptr, st);
   } else {
     rc = launch_gcn32_fwd((int)L.BT, d->S, A, (const float*)X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
-                         (int)L.Ip, st);
+                         (int)L.Ip, ws + L.ws_xtail_f, st);
   }
   if (rc != WGNN_OK) return rc;
   if (L.g32) {       // GI = [g|1] [W_ih|b_ih]^T
@@ -416,7 +418,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
                                  L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
                                  g->conv2_weight, g->conv2_bias, st);
     rc = launch_gcnx2_bwd((int)L.BT, d->S, A, Xv, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
-                          scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, st);
+                          scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, ws + L.ws_xtail_b, st);
     if (rc != WGNN_OK) return rc;
     return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3), g->conv1_weight, g->conv1_bias,
                                      g->conv2_weight, g->conv2_bias, status, st);
@@ -487,7 +489,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
                                L.I, nullptr, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
                                g->conv2_weight, g->conv2_bias, st);
   return launch_gcn32_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
-                         g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, st);
+                         g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, ws + L.ws_xtail_b, st);
 }
 }  // namespace
 

@@ -136,30 +136,31 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st);
 
 int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,
-                    const float* b1, const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
+                    const float* b1, const float* W2, const float* b2, float* g, int ldg, float* xtail_scratch, hipStream_t st);
 // two-layer backward (no dX): partial buffer >= gcn2_bwd_partial_floats() floats
 size_t gcn2_bwd_partial_floats(int ntiles);
 int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1,
                     const float* b1, const float* W2, const float* g, int ldg, const float* dg, float* dW1,
-                    float* db1, float* dW2, float* db2, float* partial, hipStream_t st);
+                    float* db1, float* dW2, float* db2, float* partial, float* xtail_scratch, hipStream_t st);
 int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
                               unsigned* status, hipStream_t st);
 // register-chained exact-fp32 variants (gcn32.hip): what the WGNN_MATH_F32 path runs
 size_t gcn32_bwd_partial_floats(int ntiles);
 int launch_gcn32_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, float* g, int ldg, hipStream_t st);
+                     const float* W2, const float* b2, float* g, int ldg, float* xtail_scratch, hipStream_t st);
 int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const float* g, int ldg, const float* dg, float* dW1, float* db1, float* dW2,
-                     float* db2, float* partial, hipStream_t st);
+                     float* db2, float* partial, float* xtail_scratch, hipStream_t st);
 // register-chained split-fp16 variants (gcnx.hip)
 size_t gcnx2_bwd_partial_floats(int ntiles);
 int gcnx_bwd_grid(int ntiles, int S, bool x3);
 // g_planes: fp16 hi plane [ntiles][ldg] followed by the lo plane; column S*13 holds 1.0, later columns 0
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io /*wgnn_io of X*/, const float* W1, const float* b1,
-                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, hipStream_t st);
+                     const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, void* xtail_scratch,
+                     hipStream_t st);   // xtail_scratch: >= S*13 + 1 elements of workspace when S*13 is odd
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
-                     int scale_in, float* partial, bool x3, hipStream_t st);
+                     int scale_in, float* partial, bool x3, void* xtail_scratch, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
                          int Rp, int Cp, unsigned* status, hipStream_t st);

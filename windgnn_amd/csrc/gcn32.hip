@@ -20,6 +20,8 @@
 
 namespace {
 #define LIVE(i, r) ((i) < NT - 1 || (r) < rl)
+// X of tile t; the tensor's last tile comes from the launcher's private copy when S*13 is odd (gcnx.hip, XLOAD)
+#define XLOAD(t) gload_pairs<NP>(xr, (xtail != nullptr && (t) == ntiles - 1) ? xtail : X + (size_t)(t) * I, lane, I)
 
 constexpr int F13 = 13;
 constexpr int FP = 16;
@@ -71,6 +73,7 @@ constexpr int FWD_WAVES = 8;
 template <int NT>
 __global__ void __launch_bounds__(64 * FWD_WAVES) gcn32_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                                   const float* __restrict__ X,
+                                                                  const float* __restrict__ xtail,
                                                                   const float* __restrict__ W1,
                                                                   const float* __restrict__ b1,
                                                                   const float* __restrict__ W2,
@@ -122,13 +125,13 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcn32_fwd_kernel(int ntiles, i
     }
   };
   if (wave_id < ntiles) {
-    gload_pairs<NP>(xr, X + (size_t)wave_id * I, lane, I);
+    XLOAD(wave_id);
     stage_x();
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     wave_lds_fence();                                          // this tile's X is staged
     const bool more = tile + nwaves < ntiles;
-    if (more) gload_pairs<NP>(xr, X + (size_t)(tile + nwaves) * I, lane, I);   // prefetch the next tile
+    if (more) XLOAD(tile + nwaves);                            // prefetch the next tile
 
     f32x4 U[NT];                                               // U1 row tile i: [s = 16 i + 4 g + r][f' = c]
 #pragma unroll
@@ -204,6 +207,7 @@ constexpr int BWD_WAVES = 12;   // 143 VGPRs = 3 waves per SIMD: one 12-wave blo
 template <int NT>
 __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                                   const float* __restrict__ X,
+                                                                  const float* __restrict__ xtail,
                                                                   const float* __restrict__ W1,
                                                                   const float* __restrict__ b1,
                                                                   const float* __restrict__ W2,
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
   float db1acc = 0.f, db2acc = 0.f;
   f32x2 xr[NP], dr[NP], gr[NP];
   if (wave_id < ntiles) {
-    gload_pairs<NP>(xr, X + (size_t)wave_id * I, lane, I);
+    XLOAD(wave_id);
     gload_pairs<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
     gload_pairs<NP>(dr, dg + (size_t)wave_id * I, lane, I);
   }
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
     wave_lds_fence();
     if (tile + nwaves < ntiles) {
       const size_t nt = (size_t)(tile + nwaves);
-      gload_pairs<NP>(xr, X + nt * I, lane, I);
+      XLOAD(tile + nwaves);
       gload_pairs<NP>(gr, gact + nt * ld_g, lane, I);
       gload_pairs<NP>(dr, dg + nt * I, lane, I);
     }
@@ -402,15 +406,30 @@ int bwd_grid(int ntiles) {
 
 size_t gcn32_bwd_partial_floats(int ntiles) { return (size_t)512 * PART; }
 
+// xtail_scratch: >= S*13 + 1 floats of workspace when S*13 is odd (XLOAD), else unused
+static int xtail32_copy(const float* X, int ntiles, int S, float* scratch, hipStream_t st, const float** xt) {
+  const size_t I = (size_t)S * 13;
+  *xt = nullptr;
+  if ((I & 1) == 0) return WGNN_OK;
+  if (!scratch) return WGNN_ERR_NULL;
+  if (hipMemcpyAsync(scratch, X + (size_t)(ntiles - 1) * I, I * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return WGNN_ERR_HIP;
+  *xt = scratch;
+  return WGNN_OK;
+}
+
 int launch_gcn32_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* b2, float* g, int ldg, hipStream_t st) {
+                     const float* W2, const float* b2, float* g, int ldg, float* xtail_scratch, hipStream_t st) {
+  const float* xt;
+  const int rc0 = xtail32_copy(X, ntiles, S, xtail_scratch, st, &xt);
+  if (rc0 != WGNN_OK) return rc0;
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
   const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
   int gx = cdiv_i(ntiles, FWD_WAVES);
   gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
 #define FCASE(NT)                                                                                                \
   PROF_LAUNCH("gcn32_fwd_kernel<" #NT ">", fl, by, st,                                                           \
-              hipLaunchKernelGGL((gcn32_fwd_kernel<NT>), dim3(gx), dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, \
+              hipLaunchKernelGGL((gcn32_fwd_kernel<NT>), dim3(gx), dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, xt, W1, b1, W2, \
                                  b2, g, ldg))
   switch ((S + 15) / 16) {
     case 1: FCASE(1); break;
@@ -426,13 +445,16 @@ int launch_gcn32_fwd(int ntiles, int S, const float* A, const float* X, const fl
 
 int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const float* g, int ldg, const float* dg, float* dW1, float* db1, float* dW2,
-                     float* db2, float* partial, hipStream_t st) {
+                     float* db2, float* partial, float* xtail_scratch, hipStream_t st) {
+  const float* xt;
+  const int rc0 = xtail32_copy(X, ntiles, S, xtail_scratch, st, &xt);
+  if (rc0 != WGNN_OK) return rc0;
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
   const int gx = bwd_grid(ntiles);
 #define BCASE(NT)                                                                                                \
   PROF_LAUNCH("gcn32_bwd_kernel<" #NT ">", fl, by, st,                                                           \
-              hipLaunchKernelGGL((gcn32_bwd_kernel<NT>), dim3(gx), dim3(64 * BWD_WAVES), 0, st, ntiles, S, A, X, W1, b1, W2, \
+              hipLaunchKernelGGL((gcn32_bwd_kernel<NT>), dim3(gx), dim3(64 * BWD_WAVES), 0, st, ntiles, S, A, X, xt, W1, b1, W2, \
                                  g, ldg, dg, partial))
   switch ((S + 15) / 16) {
     case 1: BCASE(1); break;

@@ -196,6 +196,15 @@ __device__ __forceinline__ void gload_pairs(f32x2 (&r)[NP], const float* __restr
     }
   }
 }
+// X of tile t.  With an odd tile length the last pair of a tile ends one element past it -- harmless (the next tile's
+// first element, dropped at staging) except at the tensor's LAST tile, where it would be a read past a caller-owned
+// buffer: the launcher copies that tile into scratch with one element of slack (xtail; nullptr when S*13 is even) and
+// the wave that owns it reads the copy.  A scalar select of the base address: no VGPRs, nothing in the common path.
+#define XLOAD(t)                                                                                          \
+  do {                                                                                                    \
+    const bool tl_ = xtail != nullptr && (t) == ntiles - 1;                                               \
+    gload_pairs_io<NP>(xr, tl_ ? xtail : X, tl_ ? (size_t)0 : (size_t)(t) * I, lane, I, IO ? io : 0);     \
+  } while (0)
 // The same for an io-typed tensor (wgnn_io): 16-bit pairs are one dword, kept raw in r[k][0] until io_pair() converts
 // them at staging time (so the wait for the prefetch stays where it was).  `tile_elems` = element offset of the tile.
 template <int NP>
@@ -250,7 +259,8 @@ constexpr int FWD_WAVES = 8;   // waves per forward block (A fragments are share
 // IO: X is 16-bit (fp16 / bf16 by `io`); false = fp32 (no conversion code at all in the default instance)
 template <int NT, bool X3, bool IO>
 __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, int S, const float* __restrict__ A,
-                                                       const void* __restrict__ X, int io, const float* __restrict__ W1,
+                                                       const void* __restrict__ X, const void* __restrict__ xtail, int io,
+                                                       const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const float* __restrict__ b2, _Float16* __restrict__ ghi,
                                                        _Float16* __restrict__ glo, int ldp, unsigned* status) {
@@ -328,14 +338,14 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
     }
   };
   if (wave_id < ntiles) {
-    gload_pairs_io<NP>(xr, X, (size_t)wave_id * I, lane, I, IO ? io : 0);
+    XLOAD(wave_id);
     stage_x();
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     asm volatile("" ::: "memory");                    // keep the A-fragment reads in LDS (no hoisting into VGPRs)
     wave_lds_fence();                                 // this tile's X is staged
     const bool more = tile + nwaves < ntiles;
-    if (more) gload_pairs_io<NP>(xr, X, (size_t)(tile + nwaves) * I, lane, I, IO ? io : 0);   // prefetch the next tile
+    if (more) XLOAD(tile + nwaves);                   // prefetch the next tile
 
     f32x4 U[NT];
 #pragma unroll
@@ -429,7 +439,8 @@ constexpr int bwd_waves(int NT, bool X3) { return (!X3 && NT <= 3) ? 16 : 12; }
 
 template <int NT, bool X3, bool IO>
 __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
-                                                       const void* __restrict__ X, int io, const float* __restrict__ W1,
+                                                       const void* __restrict__ X, const void* __restrict__ xtail, int io,
+                                                       const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const _Float16* __restrict__ gact, int ld_g,
                                                        const float* __restrict__ dg, const float* __restrict__ scales,
@@ -510,7 +521,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
   f32x2 xr[NP], dr[NP];
   h2 gr[NP];
   if (wave_id < ntiles) {
-    gload_pairs_io<NP>(xr, X, (size_t)wave_id * I, lane, I, IO ? io : 0);
+    XLOAD(wave_id);
     gload_pairs_h<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
     gload_pairs<NP>(dr, dg + (size_t)wave_id * I, lane, I);
   }
@@ -530,7 +541,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
     wave_lds_fence();
     if (tile + nwaves < ntiles) {                               // prefetch the next tile under this one's math
       const size_t nt = (size_t)(tile + nwaves);
-      gload_pairs_io<NP>(xr, X, nt * I, lane, I, IO ? io : 0);
+      XLOAD(tile + nwaves);
       gload_pairs_h<NP>(gr, gact + nt * ld_g, lane, I);
       gload_pairs<NP>(dr, dg + nt * I, lane, I);
     }
@@ -681,9 +692,24 @@ int grid_x(int ntiles, int S, bool x3) {
 size_t gcnx2_bwd_partial_floats(int ntiles) { return (size_t)256 * PART; }
 int gcnx_bwd_grid(int ntiles, int S, bool x3) { return grid_x(ntiles, S, x3); }
 
+// The private copy of X's last tile for odd S*13 (XLOAD): returns the scratch pointer, or nullptr when no copy is needed.
+static const void* xtail_copy(const void* X, int ntiles, int S, int io, void* scratch, hipStream_t st, int* rc) {
+  *rc = WGNN_OK;
+  const size_t I = (size_t)S * 13, es = io ? 2 : 4;
+  if ((I & 1) == 0) return nullptr;
+  if (!scratch) { *rc = WGNN_ERR_NULL; return nullptr; }
+  if (hipMemcpyAsync(scratch, (const char*)X + (size_t)(ntiles - 1) * I * es, I * es, hipMemcpyDeviceToDevice, st) !=
+      hipSuccess)
+    *rc = WGNN_ERR_HIP;
+  return scratch;
+}
+
 int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status,
-                     hipStream_t st) {
+                     void* xtail_scratch, hipStream_t st) {
+  int rc0;
+  const void* xt = xtail_copy(X, ntiles, S, io, xtail_scratch, st, &rc0);
+  if (rc0 != WGNN_OK) return rc0;
   _Float16* ghi = (_Float16*)g_planes;
   _Float16* glo = ghi + (size_t)ntiles * ldg;
   const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
@@ -693,7 +719,7 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, c
   const dim3 grid(gx);
 #define FWD_LAUNCH(NT, X3V, IOV, NAME, BYTES)                                                                     \
   PROF_LAUNCH(NAME, fl, BYTES, st,                                                                                \
-              hipLaunchKernelGGL((gcnx_fwd_kernel<NT, X3V, IOV>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, io, W1, \
+              hipLaunchKernelGGL((gcnx_fwd_kernel<NT, X3V, IOV>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, xt, io, W1, \
                                  b1, W2, b2, ghi, glo, ldg, status))
 #define FWD_CASE(NT)                                                                                              \
   if (x3 && !io) FWD_LAUNCH(NT, true, false, "gcnx_fwd_kernel<" #NT ">", by);                                     \
@@ -715,7 +741,10 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, c
 
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
-                     int scale_in, float* partial, bool x3, hipStream_t st) {
+                     int scale_in, float* partial, bool x3, void* xtail_scratch, hipStream_t st) {
+  int rc0;
+  const void* xt = xtail_copy(X, ntiles, S, io, xtail_scratch, st, &rc0);
+  if (rc0 != WGNN_OK) return rc0;
   const _Float16* g = (const _Float16*)g_planes;   // hi plane carries the sign: g > 0 <=> hi > 0
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   // what the launch reads: X and dg as fp32, and the fp16 hi plane of g (2 bytes x ldg per tile) as the ReLU mask
@@ -723,7 +752,7 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
   const dim3 grid(grid_x(ntiles, S, x3));
 #define BWD_LAUNCH(NT, X3V, IOV, NAME)                                                                            \
   PROF_LAUNCH(NAME, fl, by, st,                                                                                   \
-              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV>), grid, dim3(64 * bwd_waves(NT, X3V)), 0, st, ntiles, S, A, X, io, \
+              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV>), grid, dim3(64 * bwd_waves(NT, X3V)), 0, st, ntiles, S, A, X, xt, io, \
                                  W1, b1, W2, g, ldg, dg, scales, scale_in, partial))
 #define BWD_CASE(NT)                                                                                              \
   if (x3 && !io) BWD_LAUNCH(NT, true, false, "gcnx_bwd_kernel<" #NT ">");                                         \
