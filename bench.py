@@ -10,8 +10,9 @@ timed region; every arithmetic op of the step is a libwindgnn_hip.so kernel.
 
 Order of a default N = 1 run: (1) two short child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then
 WRITE_SIZE: the counters cannot share a pass) measure the HBM traffic of every kernel of THIS build, before this
-process touches the GPU; (2) warm-up + the timed steps; (3) a per-kernel pass with hipEvents inside the library;
-(4) forward-only timing; (5) the exact-fp32 mode on the same workload (secondary value); (6) the CPU baselines."""
+process touches the GPU; (2) a per-kernel pass with hipEvents inside the library and the forward-only timing (so the
+GPU does not enter the timed region cold); (3) `warmup` untimed steps + exactly `steps` timed steps; (4) the exact-fp32
+mode on the same workload (secondary value); (5) the CPU baselines."""
 import argparse
 import json
 import os
@@ -233,6 +234,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- measurement passes that are not the timed region come FIRST (every rank runs them, rank 0 keeps the numbers):
+    # the per-kernel pass (hipEvents inside the library) and the forward-only timing.  A 20 + 20 step run is 33 ms of GPU
+    # time; entered cold it times the clock ramp (round 1: 4.59 M windows/s in the driver's 20-step run vs 4.85 M over 200
+    # steps of the same code).  The timed region below is still exactly `warmup` untimed + `steps` timed steps.
+    recs, fwd_s = None, None
+    if not args.traffic_child:
+        from windgnn_amd.functional import gcn_gru_forward_raw
+        for _ in range(max(args.warmup, 20) if args.workload == "c3" else args.warmup):   # untimed: first launches, clock ramp
+            trainer.forward_backward(A, X, L)
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        for _ in range(args.steps):
+            trainer.forward_backward(A, X, L)
+        torch.cuda.synchronize()
+        recs = _lib.profile_read()
+        _lib.profile_enable(False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            gcn_gru_forward_raw(A, X, trainer.p_views, model.math, want_stash=False)
+        e1.record()
+        torch.cuda.synchronize()
+        fwd_s = e0.elapsed_time(e1) * 1e-3 / args.steps
+
     for _ in range(args.warmup):
         trainer.step(A, X, L)
     barrier()
@@ -252,12 +277,6 @@ def main():
     # ---- per-kernel pass (same workload, hipEvents inside the library) for the roofline object
     roofline, forward, kernels, mfma, path, secondary = None, None, None, None, None, None
     if rank == 0:
-        _lib.profile_enable(True)
-        for _ in range(args.steps):
-            trainer.forward_backward(A, X, L)
-        torch.cuda.synchronize()
-        recs = _lib.profile_read()
-        _lib.profile_enable(False)
         recs.sort(key=lambda r: -r["ms"])
         kernels = []
         for r in recs:
@@ -316,15 +335,6 @@ def main():
             path["traffic_vs_algorithmic"] = round(tot / alg_step, 2)
             path["traffic_GBs"] = round(tot / step_s / 1e9, 1)
         # forward-only timing: north-star "fused forward vs HBM roofline" (52 224 algorithmic B/window)
-        from windgnn_amd.functional import gcn_gru_forward_raw
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
-            gcn_gru_forward_raw(A, X, trainer.p_views, model.math, want_stash=False)
-        e1.record()
-        torch.cuda.synchronize()
-        fwd_s = e0.elapsed_time(e1) * 1e-3 / args.steps
         fwd_bytes = B * T * (S * F + H) * esz
         forward = {"us": round(fwd_s * 1e6, 1), "algorithmic_GBs": round(fwd_bytes / fwd_s / 1e9, 1),
                    "hbm_frac": round(fwd_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
@@ -375,6 +385,8 @@ def main():
             "forward": forward,
             "exact_f32": secondary,
             "kernels": kernels,
+            "kernels_note": "hipEvent-bracketed inside the library: every launch carries 1-2 us of event latency, so the sum "
+                            "runs 3-4 % above ms_per_step; the rocprofv3 durations (profiles/*_kernel_stats.csv) sum to it",
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             out["cpu_baseline"] = cpu_baseline()
