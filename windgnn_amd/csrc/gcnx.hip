@@ -56,13 +56,18 @@ __device__ __forceinline__ f32x4 mfma3(const Frag& a, const Frag& b, f32x4 c) {
   c = mfma_x(a.hi, b.hi, c);
   return c;
 }
+// (one-pass fp16 mode: the K = 32 form on the same half fragments, whose slots j >= 4 are zero, into the product's one
+// accumulator -- that instance is bound by its dependent chain, not by VALU issue: with the mixed forms and their extra
+// accumulators it took 129-139 us, like this 122; full-depth operands as before the half fragments: 128)
 template <bool X3>
 __device__ __forceinline__ f32x4 mfma3h(const Frag& a, const Frag& b, f32x4 c) {
   if (X3) {
     c = mfma_h(a.lo, b.hi, c);
     c = mfma_h(a.hi, b.lo, c);
+    c = mfma_h(a.hi, b.hi, c);
+  } else {
+    c = mfma_x(a.hi, b.hi, c);
   }
-  c = mfma_h(a.hi, b.hi, c);
   return c;
 }
 // hi = fp16(x) (v_cvt_pk_f16_f32, 2 values per instruction), lo = fp16(x - hi) with the difference
@@ -361,9 +366,10 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (2 * ks + 1 < NT) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
-        else acc16 = mfma3h<X3>(UF[ks], ldA(n, ks), acc16);
+        else if (X3) acc16 = mfma3h<X3>(UF[ks], ldA(n, ks), acc16);
+        else acc = mfma3h<X3>(UF[ks], ldA(n, ks), acc);
       }
-      if (NT & 1) acc += acc16;
+      if (X3 && (NT & 1)) acc += acc16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         Ht[n][r] = relu_nan(acc[r] + bb1[r]);
@@ -380,9 +386,10 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (2 * ks + 1 < NT) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
-        else acc16 = mfma3h<X3>(UF[ks], ldA(n, ks), acc16);
+        else if (X3) acc16 = mfma3h<X3>(UF[ks], ldA(n, ks), acc16);
+        else acc = mfma3h<X3>(UF[ks], ldA(n, ks), acc);
       }
-      if (NT & 1) acc += acc16;
+      if (X3 && (NT & 1)) acc += acc16;
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -560,9 +567,10 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (2 * ks + 1 < NT) acc = mfma3<X3>(ldA(mi, ks), UF[ks], acc);
-        else acc16 = mfma3h<X3>(ldA(mi, ks), UF[ks], acc16);
+        else if (X3) acc16 = mfma3h<X3>(ldA(mi, ks), UF[ks], acc16);
+        else acc = mfma3h<X3>(ldA(mi, ks), UF[ks], acc);
       }
-      if (NT & 1) acc += acc16;
+      if (X3 && (NT & 1)) acc += acc16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s = 16 * mi + 4 * g + r;
@@ -591,17 +599,20 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (2 * ks + 1 < NT) acc = mfma3<X3>(ldT(mi, ks), DZF[ks], acc);
-        else acc16 = mfma3h<X3>(ldT(mi, ks), DZF[ks], acc16);
+        else if (X3) acc16 = mfma3h<X3>(ldT(mi, ks), DZF[ks], acc16);
+        else acc = mfma3h<X3>(ldT(mi, ks), DZF[ks], acc);
       }
-      if (NT & 1) acc += acc16;
+      if (X3 && (NT & 1)) acc += acc16;
       dU[mi] = acc;
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (2 * ks + 1 < NT)
         dW2acc = mfma3<X3>(frag_of<X3>(H1[2 * ks], H1[2 * ks + 1]), frag_of<X3>(dU[2 * ks], dU[2 * ks + 1]), dW2acc);
-      else
+      else if (X3)
         dW2acc16 = mfma3h<X3>(frag_half<X3>(H1[2 * ks]), frag_half<X3>(dU[2 * ks]), dW2acc16);
+      else
+        dW2acc = mfma3h<X3>(frag_half<X3>(H1[2 * ks]), frag_half<X3>(dU[2 * ks]), dW2acc);
     }
     // ---- dH1 [s'][f] = dU2 W2^T contracts over dU2's COLUMN index: dU2 goes through the wave's staging buffer
     // (the dZ2 tile in it has been consumed) and comes back as natural-k A fragments -- 12 ds_write_b32 + 6
@@ -632,9 +643,10 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (2 * ks + 1 < NT) acc = mfma3<X3>(ldT(mi, ks), DZF[ks], acc);
-        else acc16 = mfma3h<X3>(ldT(mi, ks), DZF[ks], acc16);
+        else if (X3) acc16 = mfma3h<X3>(ldT(mi, ks), DZF[ks], acc16);
+        else acc = mfma3h<X3>(ldT(mi, ks), DZF[ks], acc);
       }
-      if (NT & 1) acc += acc16;
+      if (X3 && (NT & 1)) acc += acc16;
       dU[mi] = acc;
     }
     f32x4 XC[NT];
@@ -646,8 +658,10 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
     for (int ks = 0; ks < KS; ++ks) {
       if (2 * ks + 1 < NT)
         dW1acc = mfma3<X3>(frag_of<X3>(XC[2 * ks], XC[2 * ks + 1]), frag_of<X3>(dU[2 * ks], dU[2 * ks + 1]), dW1acc);
-      else
+      else if (X3)
         dW1acc16 = mfma3h<X3>(frag_half<X3>(XC[2 * ks]), frag_half<X3>(dU[2 * ks]), dW1acc16);
+      else
+        dW1acc = mfma3h<X3>(frag_half<X3>(XC[2 * ks]), frag_half<X3>(dU[2 * ks]), dW1acc);
     }
   }
 
