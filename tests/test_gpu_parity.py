@@ -87,6 +87,34 @@ def test_against_oracle_random(S, T, B, H, math):
         assert rel_to_max(grads[k], go[k]) <= G_TOL, k
 
 
+@pytest.mark.parametrize("math", ["f32", "f16x3", "f16"])
+def test_random_shape_sweep(math):
+    """24 seeded random shapes per math mode (S 1..64, T 1..9, B 1..48, H 1..128: every row-tile count of the GCN kernels,
+    odd and even S*13, recurrence widths on both sides of every padding boundary) through the module, against the fp64
+    oracle at the mode's tolerance."""
+    import random
+    from oracle import windgnn_oracle as orc
+    dev = _dev()
+    rnd = random.Random(20260 + len(math))
+    # one-pass fp16: twice the golden-fixture gradient tolerance -- shapes with a handful of windows average less
+    # rounding noise than the fixtures do (worst case here: 5.1e-2 on conv1.weight at S = 47, T = 2, B = 6, H = 10)
+    y_tol, g_tol = (F16_Y_TOL, 2 * F16_G_TOL) if math == "f16" else (Y_TOL, G_TOL)
+    for case in range(24):
+        S, T, B, H = rnd.randint(1, 64), rnd.randint(1, 9), rnd.randint(1, 48), rnd.randint(1, 128)
+        g = torch.Generator().manual_seed(7000 + case)
+        A = torch.rand(S, S, generator=g) / S + 0.01
+        X = torch.rand(B, T, S, 13, generator=g)
+        L = torch.rand(B, T, H, generator=g)
+        p = orc.init_params(S, 13, H, seed=100 + case)
+        Yo, loss_o, go = orc.train_step(A.double(), X.double(), L.double(), {k: v.double() for k, v in p.items()})
+        model = _model_from(p, S, H, math)
+        out, loss, grads = _run_step(model, A.to(dev), X.to(dev), L.to(dev))
+        tag = (case, S, T, B, H)
+        assert max_abs(out.reshape(Yo.shape), Yo) <= y_tol, tag
+        for k in PARAM_KEYS:
+            assert rel_to_max(grads[k], go[k]) <= g_tol, (tag, k)
+
+
 def test_graph_conv_layer_module_with_input_grad():
     """GraphConvLayer alone (src/step5_gcn_layer_model.py), including dX for a stacked use."""
     from windgnn_amd import GraphConvLayer
