@@ -100,13 +100,8 @@ __global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, 
         if (jv && b < B) {
           const size_t bt = (size_t)b * T + t;
           Y[bt * H + j] = hnew[r];
-          if (gates) {
-            float* gp = gates + bt * 4 * H;
-            gp[j] = rg;
-            gp[H + j] = zg;
-            gp[2 * H + j] = ng;
-            gp[3 * H + j] = an[r];
-          }
+          if (gates)   // one 16-byte record (r, z, n, gh_n) per element: [bt][j][4], read back as one load by gru_bwd
+            *(f32x4*)(gates + (bt * H + j) * 4) = f32x4{rg, zg, ng, an[r]};
         }
       }
     }
@@ -167,12 +162,12 @@ __global__ void __launch_bounds__(NTHREADS) gru_bwd_kernel(int B, int T, int H, 
       const int b = b0 + 4 * lk + r;
       const bool ok = jv && b < B && t >= 0;
       const size_t bt = (size_t)(ok ? b : 0) * T + (ok ? t : 0);
-      const float* gp = gates + bt * 4 * H;
+      const f32x4 gq = ok ? *(const f32x4*)(gates + (bt * H + j) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};   // gru_fwd's record
       s.dy[r] = ok ? dY[bt * H + j] : 0.f;
-      s.r[r] = ok ? gp[j] : 0.f;
-      s.z[r] = ok ? gp[H + j] : 0.f;
-      s.n[r] = ok ? gp[2 * H + j] : 0.f;
-      s.ghn[r] = ok ? gp[3 * H + j] : 0.f;
+      s.r[r] = gq[0];
+      s.z[r] = gq[1];
+      s.n[r] = gq[2];
+      s.ghn[r] = gq[3];
       s.hp[r] = (ok && t > 0) ? Y[(bt - 1) * H + j] : 0.f;
     }
   };
