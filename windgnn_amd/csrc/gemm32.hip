@@ -1,14 +1,15 @@
-// Exact-fp32 GEMMs for large B*T (WGNN_MATH_F32): the GRU input projection, its backward and dW_ih on
-// v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 with the structure of the plane GEMMs (pgemm.hip): ONE large workgroup
-// per CU, operands staged by LDS-DMA (global_load_lds_dwordx4) exactly as they lie in HBM into a two-stage ring,
+// Exact-fp32 GEMMs (WGNN_MATH_F32) for B*T >= 4096 (GI, dg) / >= 24576 (dW_ih, dW_hh): the GRU input projection, its
+// backward and the weight gradients on v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 with the structure of the plane
+// GEMMs (pgemm.hip): one large workgroup per CU, operands staged by LDS-DMA (global_load_lds_dwordx4) exactly as they lie in HBM into a two-stage ring,
 // fragments read with wide LDS loads, no per-element bounds code in the main loop.  That needs operands whose rows are
 // 16-byte aligned and whose K extent is padded with finite values: g [B*T][Ip] (ones column at I, zeros after: written by
 // gcn32_fwd), dGI [B*T][Gp] (zero padding written by the recurrences' backward) and zero-padded copies of W_ih / W_ih^T
 // (pad_weight_kernel below, two ~3 us launches per step).  fp32 MFMA sustains 149 TFLOP/s here (tools/mfma_rate.hip);
-// the register-staged general kernel of gemm.hip (kept for small B*T, dW_hh and the wide-GRU paths) reaches 72.
+// the register-staged general kernel of gemm.hip (kept for small B*T and the wide-GRU / CSR paths) reaches 72.
 //
 //   NT  C[M][N] = A[M][Kp] . Bp[N][Kp]^T      GI = [g|1] [W_ih|b_ih]^T,   dg = dGI (W_ih^T)^T
-//   TN  P[z][Mo][No] = sum_k A[k][m] B[k][n]  dW_ih|db_ih = dGI^T [g|1]   (split-K, reduced by splitk_reduce_kernel)
+//   TN  P[z][Mo][No] = sum_k A[k][m] B[k][n]  dW_ih|db_ih = dGI^T [g|1], dW_hh|db_hh = dGH^T [Hprev|1]
+//                                              (split-K, reduced by splitk_reduce_kernel)
 #include <string>
 
 #include "common.h"
@@ -20,7 +21,7 @@ typedef __attribute__((address_space(1))) const void glb_void;
 
 // ------------------------------------------------------------------------------------------------
 // NT.  MW (M) x NW (N) waves; wave tile 32 x 32 T32, workgroup tile 32 MW x 32 T32 NW; K step 32 = one 128-byte LDS row.
-// Two forms: 4 x 2 waves with T32 <= 7 (128-row tiles, one workgroup per CU: B*T >= 24576) and 1 x NW waves with
+// Two forms: 4 x 2 waves with T32 <= 7 (128-row tiles, one workgroup per CU: from 192 such tiles) and 1 x NW waves with
 // T32 = 1 (32-row tiles, one wave per 32 output columns: a few thousand rows still give most CUs a workgroup).
 // A k group of 8 = two 16-byte chunks: lane (i, kh) of the 32x32x2 MFMA reads chunk 2 kk + kh of row i as ONE
 // ds_read_b128; its element jj is the operand of MFMA jj, whose two k slots are therefore k = 8 kk + jj and 8 kk + 4 + jj
