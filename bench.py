@@ -384,6 +384,7 @@ def main():
             "mfma": mfma,
             "forward": forward,
             "exact_f32": secondary,
+            "measurement_order": "traffic children (N=1), untimed per-kernel pass + forward timing, then `warmup` untimed and `steps` timed steps, secondary, cpu baseline",
             "kernels": kernels,
             "kernels_note": "hipEvent-bracketed inside the library: every launch carries 1-2 us of event latency, so the sum "
                             "runs 3-4 % above ms_per_step; the rocprofv3 durations (profiles/*_kernel_stats.csv) sum to it",
