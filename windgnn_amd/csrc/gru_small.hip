@@ -108,13 +108,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
         if (b < B) {
           const size_t bt = (size_t)b * T + t;
           Y[bt * H + j] = hnew;
-          if (gates) {
-            float* gp = gates + bt * 4 * H;
-            gp[j] = rg;
-            gp[H + j] = zg;
-            gp[2 * H + j] = ng;
-            gp[3 * H + j] = ghn;
-          }
+          if (gates)   // one 16-byte record (r, z, n, gh_n) per element, [bt][j][4] (as gru.hip)
+            *(f32x4*)(gates + (bt * H + j) * 4) = f32x4{rg, zg, ng, ghn};
         }
       }
     }
@@ -170,13 +165,13 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
     for (int wdw = 0; wdw < WPB; ++wdw) {
       const int b = b0 + wdw < B ? b0 + wdw : B - 1;
       const size_t bt = (size_t)b * T + tc;
-      const float* gp = gates + bt * 4 * H;
       const int jj = i;
+      const f32x4 gq = *(const f32x4*)(gates + (bt * H + jj) * 4);   // the forward's (r, z, n, gh_n) record
       s[wdw].dy = dY[bt * H + jj];
-      s[wdw].r = gp[jj];
-      s[wdw].z = gp[H + jj];
-      s[wdw].n = gp[2 * H + jj];
-      s[wdw].ghn = gp[3 * H + jj];
+      s[wdw].r = gq[0];
+      s[wdw].z = gq[1];
+      s[wdw].n = gq[2];
+      s[wdw].ghn = gq[3];
       const float hp = Y[(bt - (tc > 0 ? 1 : 0)) * H + jj];
       s[wdw].hp = tc > 0 ? hp : 0.f;
     }
