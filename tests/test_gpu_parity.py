@@ -301,11 +301,10 @@ def test_full_size_properties_B4096(math):
 
 @pytest.mark.parametrize("S,T,B,H", [(34, 24, 1100, 102), (7, 24, 1100, 21), (20, 30, 900, 64), (34, 24, 1500, 128)])
 def test_exact_fp32_big_tile_gemms(S, T, B, H):
-    """Exact-fp32 mode at B*T >= 24576 runs GI / dg on the 128-row LDS-DMA GEMM tiles and dW_ih / dW_hh on the split-K
-    LDS-DMA kernel (csrc/gemm32.hip); two half batches take the 32-row NT form and the general split-K kernel
-    (csrc/gemm.hip).  The two routes must agree to fp32 rounding (Y per window, gradients summed over the halves), and
-    the big route must agree with the fp64 oracle (first shape).  (Below B*T = 4096 everything is the general kernel:
-    the golden-fixture tests; B = 256, T = 24 against the oracle covers the 32-row form.)"""
+    """Exact-fp32 mode at B*T >= 24576 runs GI / dg on the 128-row LDS-DMA GEMM tiles (csrc/gemm32.hip); two half
+    batches take the 32-row NT form and other split-K chunkings of the dW products.  The two routes must agree to fp32
+    rounding (Y per window, gradients summed over the halves), and the big route must agree with the fp64 oracle (first
+    shape).  (Below B*T = 4096 everything is the general kernel of csrc/gemm.hip: the golden-fixture tests.)"""
     from oracle import windgnn_oracle as orc
     from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
     dev = _dev()
@@ -344,7 +343,8 @@ def test_exact_fp32_big_tile_gemms(S, T, B, H):
 @pytest.mark.parametrize("S,T,B,H", [(5, 30, 140, 10), (20, 24, 200, 40), (34, 24, 180, 102), (13, 24, 300, 128)])
 def test_exact_fp32_32row_gemms_against_oracle(S, T, B, H):
     """4096 <= B*T < 24576 in exact fp32: GI and dg run on the 32-row form of the LDS-DMA NT kernel (csrc/gemm32.hip:
-    one wave per 32 output columns, 1..14 waves), the dW products on the general split-K kernel.  Whole batch against
+    one wave per 32 output columns, 1..14 waves), the dW products on the split-K LDS-DMA kernel with two-stage K chunks
+    (some of them empty at these sizes).  Whole batch against
     the fp64 oracle at the fp32 tolerance (several widths: 3H = 30..384 and S*13 = 65..442 output columns).
     (Input seed: with seed 17 one layer-1 pre-activation of the S = 13 case is -7e-9 in fp64 and +1e-8 in fp32, a ReLU
     tie that moves conv1's gradient by one term, 7e-4 of max; with 31 none of the four cases has |z| < 5e-7.)"""

@@ -1,4 +1,4 @@
-// Exact-fp32 GEMMs (WGNN_MATH_F32) for B*T >= 4096 (GI, dg) / >= 24576 (dW_ih, dW_hh): the GRU input projection, its
+// Exact-fp32 GEMMs (WGNN_MATH_F32) for B*T >= 4096: the GRU input projection, its
 // backward and the weight gradients on v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 with the structure of the plane
 // GEMMs (pgemm.hip): one large workgroup per CU, operands staged by LDS-DMA (global_load_lds_dwordx4) exactly as they lie in HBM into a two-stage ring,
 // fragments read with wide LDS loads, no per-element bounds code in the main loop.  That needs operands whose rows are
@@ -320,12 +320,11 @@ int gemm32_nt_rows(int N) {
 }
 
 // The LDS-DMA kernels need the contraction padded to 32 and short enough for a single fp32 accumulation chain (the
-// general kernel folds every 512).  NT pays off from a few thousand rows (32-row tiles), the split-K TN form once every
-// CU has a K chunk of several stages.
+// general kernel folds every 512).  Both pay off from a few thousand rows (NT: 32-row tiles; TN: K chunks of two stages).
 bool gemm32_nt_supported(size_t BT, int Kp_f, int Kp_b) {
   return BT >= 4096 && Kp_f % 32 == 0 && Kp_b % 32 == 0 && Kp_f <= 512 && Kp_b <= 512;
 }
-bool gemm32_tn_supported(size_t BT) { return BT >= 24576; }
+bool gemm32_tn_supported(size_t BT) { return BT >= 4096; }
 
 int launch_pad_weight(const float* W, int R, int C, int transpose, const float* bias, float* out, int Ro, int Co,
                       hipStream_t st) {
