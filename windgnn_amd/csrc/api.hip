@@ -56,7 +56,7 @@ Layout make_layout(const wgnn_dims* d) {
   auto al = [](size_t x) { return align_up(x, 64); };
   // exact fp32 at large B*T: the big-tile GEMMs of gemm32.hip on zero-padded copies of W_ih / W_ih^T
   L.g32 = !x3 && !L.gen_gcn && !L.gen_gru && gemm32_nt_supported(L.BT, (int)L.Ip, (int)L.Gp);
-  L.g32tn = L.g32 && gemm32_tn_supported(L.BT);          // the split-K dW products need more rows than GI / dg
+  L.g32tn = L.g32 && gemm32_tn_supported(L.BT);          // the split-K dW products (same threshold today)
   const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : (L.g32 ? (size_t)gemm32_nt_rows((int)L.G3) * L.Ip : 0);   // 2 planes of halfs = that many floats
   const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : (L.g32 ? (size_t)gemm32_nt_rows((int)L.I) * L.Gp : 0);
   constexpr size_t HDR = WGNN_STATUS_BYTES / sizeof(float);   // status block at the start of the workspace
