@@ -32,7 +32,7 @@ S, T, F, H = 34, 24, 13, 102
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
 # which roofline bounds each kernel (DESIGN.md "Kernels")
-BOUND_HBM_PREFIXES = ("mse_", "adam_", "amax_", "splitk_reduce", "tn_reduce", "split_weight", "gcn_partial", "csr_", "gru_cell")
+BOUND_HBM_PREFIXES = ("mse_", "adam_", "finish_", "amax_", "splitk_reduce", "tn_reduce", "split_weight", "gcn_partial", "csr_", "gru_cell")
 
 
 def committed_traffic():
@@ -166,6 +166,43 @@ def cpu_baseline(budget_s=10.0, Bc=1024, faithful_budget_s=8.0):
                          "sample": "%d sequential B=1 steps as src/main.py:65-80 (%s), %.1f s" % (m, shape, dt1)}}
 
 
+def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
+    """One more configuration timed on the same box: `nsteps` full training steps (TrainStep.step) after 3 warm-up steps,
+    inputs resident; with `forward` also the forward-only time against its own algorithmic bytes (X + Y in the I/O type)."""
+    from windgnn_amd import GCN_GRU
+    from windgnn_amd.functional import gcn_gru_forward_raw
+    from windgnn_amd.trainer import TrainStep
+    torch.manual_seed(0)
+    m = GCN_GRU(F, F, F, S * F, H, math=math).to(dev)
+    tr = TrainStep(m)
+    X, L = make_inputs(B, 0, dev, S, H, io)
+    for _ in range(3):
+        tr.step(A, X, L)
+    torch.cuda.synchronize()
+    s0 = time.perf_counter()
+    for _ in range(nsteps):
+        tr.step(A, X, L)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - s0
+    tr.check()
+    out = {"dtype": {"f32": "f32", "f16x3": "f16x3(split-fp32)", "f16": "f16"}[math] + ("" if io == "fp32" else " math, %s I/O" % io),
+           "value": round(B * nsteps / dt, 1), "unit": "windows/s", "ms_per_step": round(1e3 * dt / nsteps, 4),
+           "steps": nsteps, "batch": B, "note": note}
+    if forward:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(nsteps):
+            gcn_gru_forward_raw(A, X, tr.p_views, m.math, want_stash=False, prepared=tr._prepared)
+        e1.record()
+        torch.cuda.synchronize()
+        fs = e0.elapsed_time(e1) * 1e-3 / nsteps
+        esz = 4.0 if io == "fp32" else 2.0
+        fb = B * T * (S * F + H) * esz
+        out["forward"] = {"us": round(fs * 1e6, 1), "algorithmic_bytes_per_window": int(T * (S * F + H) * esz),
+                          "algorithmic_GBs": round(fb / fs / 1e9, 1), "hbm_frac": round(fb / fs / 1e9 / HBM_PEAK_GBS, 4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +222,11 @@ def main():
                     help="initialise the RCCL process group and run the collective step even with one rank (rehearses the "
                          "N > 1 code path on a one-GPU box; launch with torch.distributed.run --nproc-per-node 1)")
     args = ap.parse_args()
+
+    # RCCL on this pool needs dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0): exported here, before anything initialises the
+    # GPU, so the line does not depend on the launcher's environment (windgnn_amd/distributed.py)
+    from windgnn_amd.distributed import ensure_rccl_env
+    ensure_rccl_env()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -242,28 +284,29 @@ def main():
     if not args.traffic_child:
         from windgnn_amd.functional import gcn_gru_forward_raw
         for _ in range(max(args.warmup, 20) if args.workload == "c3" else args.warmup):   # untimed: first launches, clock ramp
-            trainer.forward_backward(A, X, L)
+            trainer.step(A, X, L, world * B)
         torch.cuda.synchronize()
         _lib.profile_enable(True)
         for _ in range(args.steps):
-            trainer.forward_backward(A, X, L)
+            trainer.step(A, X, L, world * B)        # the kernels of the timed step, optimiser tail included
         torch.cuda.synchronize()
         recs = _lib.profile_read()
         _lib.profile_enable(False)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.steps):
-            gcn_gru_forward_raw(A, X, trainer.p_views, model.math, want_stash=False)
+            gcn_gru_forward_raw(A, X, trainer.p_views, model.math, want_stash=False, prepared=trainer._prepared)
         e1.record()
         torch.cuda.synchronize()
         fwd_s = e0.elapsed_time(e1) * 1e-3 / args.steps
 
+    n_global = world * B                                # fixed global batch: the exchange needs no count collective
     for _ in range(args.warmup):
-        trainer.step(A, X, L)
+        trainer.step(A, X, L, n_global)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = trainer.step(A, X, L)
+        loss, _ = trainer.step(A, X, L, n_global)
     barrier()
     dt = time.perf_counter() - t0
     if args.traffic_child:
@@ -275,7 +318,7 @@ def main():
         dt = float(tmax.item())
 
     # ---- per-kernel pass (same workload, hipEvents inside the library) for the roofline object
-    roofline, forward, kernels, mfma, path, secondary = None, None, None, None, None, None
+    roofline, forward, kernels, mfma, path, secondary, extra = None, None, None, None, None, None, {}
     if rank == 0:
         recs.sort(key=lambda r: -r["ms"])
         kernels = []
@@ -330,7 +373,6 @@ def main():
         if traffic:
             tot = sum(k["traffic_bytes_per_launch"] * k["launches_per_step"] for k in kernels
                       if k["traffic_bytes_per_launch"])
-            tot += sum(v["bytes_per_launch"] for n, v in traffic.items() if n == "adam_kernel")   # the optimiser step
             path["traffic_bytes_per_step"] = round(tot)
             path["traffic_vs_algorithmic"] = round(tot / alg_step, 2)
             path["traffic_GBs"] = round(tot / step_s / 1e9, 1)
@@ -339,23 +381,20 @@ def main():
         forward = {"us": round(fwd_s * 1e6, 1), "algorithmic_GBs": round(fwd_bytes / fwd_s / 1e9, 1),
                    "hbm_frac": round(fwd_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
                    "windows_per_s": round(B / fwd_s, 1)}
-        # ---- secondary: the same workload in the exact-fp32 mode (bitwise fp32 fmaf chains, fp32 MFMA)
-        if world == 1 and args.math != "f32" and args.workload == "c3" and not args.no_secondary and args.io == "fp32":
-            m32 = GCN_GRU(F, F, F, S * F, H, math="f32").to(dev)
-            t32 = TrainStep(m32)
-            n32 = max(5, min(args.steps, 30))
-            for _ in range(3):
-                t32.step(A, X, L)
-            torch.cuda.synchronize()
-            s0 = time.perf_counter()
-            for _ in range(n32):
-                t32.step(A, X, L)
-            torch.cuda.synchronize()
-            d32 = time.perf_counter() - s0
-            secondary = {"dtype": "f32", "value": round(B * n32 / d32, 1), "unit": "windows/s",
-                         "ms_per_step": round(1e3 * d32 / n32, 4), "steps": n32,
-                         "note": "same workload and step, WGNN_MATH_F32 (fp32-input MFMA, bitwise fp32 fmaf chains)"}
-            del t32, m32
+        # ---- secondaries on the same box, each a labelled dtype of its own (never folded into `value`):
+        #   exact_f32            the headline workload in WGNN_MATH_F32 (bitwise fp32 fmaf chains, fp32-input MFMA)
+        #   c1_f32_b256          BASELINE configs[1]: B = 256, exact fp32 (the parity config)
+        #   c2_f16_bf16io_b4096  BASELINE configs[2] literally: one-pass fp16 MFMA, bf16 X / Y / labels, B = 4096
+        if world == 1 and args.math == "f16x3" and args.workload == "c3" and not args.no_secondary and args.io == "fp32" \
+                and args.batch is None:
+            secondary = secondary_config("f32", "fp32", B, A, dev, max(5, min(args.steps, 30)),
+                                         "same workload and step, WGNN_MATH_F32 (fp32-input MFMA, bitwise fp32 fmaf chains)")
+            extra["c1_f32_b256"] = secondary_config("f32", "fp32", 256, A, dev, max(10, min(2 * args.steps, 60)),
+                                                    "BASELINE configs[1]: S=34, T=24, B=256, exact fp32 math and I/O")
+            extra["c2_f16_bf16io_b4096"] = secondary_config(
+                "f16", "bf16", 4096, A, dev, max(5, min(args.steps, 30)),
+                "BASELINE configs[2]: S=34, T=24, B=4096, one-pass fp16 MFMA (fp32 accumulate), bf16 X / Y / labels; "
+                "own tolerance (Y 2e-2), never the fp32-parity number", forward=True)
 
     if rank == 0:
         out = {
@@ -384,7 +423,9 @@ def main():
             "mfma": mfma,
             "forward": forward,
             "exact_f32": secondary,
-            "measurement_order": "traffic children (N=1), untimed per-kernel pass + forward timing, then `warmup` untimed and `steps` timed steps, secondary, cpu baseline",
+            "c1_f32_b256": extra.get("c1_f32_b256"),
+            "c2_f16_bf16io_b4096": extra.get("c2_f16_bf16io_b4096"),
+            "measurement_order": "traffic children (N=1), untimed per-kernel pass + forward timing, then `warmup` untimed and `steps` timed steps, secondaries (exact_f32, c1, c2), cpu baseline",
             "kernels": kernels,
             "kernels_note": "hipEvent-bracketed inside the library: every launch carries 1-2 us of event latency, so the sum "
                             "runs 3-4 % above ms_per_step; the rocprofv3 durations (profiles/*_kernel_stats.csv) sum to it",

@@ -19,7 +19,8 @@
  *     the library allocates nothing persistent and frees nothing.  Process-wide state is limited to: a
  *     per-kernel "opted into > 64 KB of dynamic LDS on device d" bit set (written once per device, atomically)
  *     and the wgnn_profile_* measurement aid (off by default, not thread-safe).
- *   - All tensors are contiguous fp32 in the reference's layouts:
+ *   - All tensors are contiguous, in the reference's layouts; fp32, except X, Y and the labels, which have the element
+ *     type wgnn_dims.io names (fp32 by default, fp16 / bf16 with the fp16-plane math modes):
  *       A [S,S] row-major (or CSR, see wgnn_adj_format), X [B,T,S,F] (F fastest), Y [B,T,H], L [B,T,H],
  *       conv*.weight [F,F] (in,out), conv*.bias [F], w_ih [3H, S*F], w_hh [3H,H], b_ih/b_hh [3H],
  *       GRU gate row order r,z,n (torch nn.GRU).
@@ -38,13 +39,13 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 110 /* 0.1.1 */
+#define WGNN_VERSION 120 /* 0.1.2: wgnn_params.prepared, wgnn_finish, WGNN_BWD_DEFER */
 
 /* Status block: the first 256 bytes of every `workspace` passed to wgnn_fwd / wgnn_bwd* belong to the library as a
  * sticky status area that kernels only ever OR into; word 0 (uint32) holds the bits below.  The caller zeroes the
  * workspace once when it allocates it, may read word 0 whenever it synchronises anyway, and clears it after
  * handling an error.  The fp16-plane math modes (WGNN_MATH_F16X3 / WGNN_MATH_F16) hold activations and weights as
- * fp16 (hi [+ lo]) and cannot represent magnitudes >= 65520; the reference's fp32 path has no such limit, so
+ * fp16 (hi [+ lo]) and cannot represent magnitudes > 65504 (anything beyond is flagged); the reference's fp32 path has no such limit, so
  * instead of producing inf/NaN (or, behind a ReLU, silently 0) the kernels report it here.  WGNN_MATH_F32 never
  * sets a bit. */
 #define WGNN_STATUS_BYTES 256
@@ -63,7 +64,7 @@ typedef enum wgnn_status {
   WGNN_ERR_RANGE = -7        /* host bindings raise this when they read a non-zero status word (see Status block) */
 } wgnn_status;
 
-/* math mode of the contractions (I/O is always fp32) */
+/* math mode of the contractions (the element type of X / Y / labels is wgnn_dims.io, see wgnn_io) */
 typedef enum wgnn_math {
   WGNN_MATH_F32 = 0,   /* fp32-input MFMA: bitwise an fp32 fmaf chain */
   WGNN_MATH_F16X3 = 1, /* split-fp16 (hi+lo) MFMA, 3 products, fp32 accumulate: fp32-grade error */
@@ -110,6 +111,12 @@ typedef struct wgnn_params {
   const float* w_hh;         /* gru.weight_hh_l0 [3H, H]   */
   const float* b_ih;         /* gru.bias_ih_l0   [3H]      */
   const float* b_hh;         /* gru.bias_hh_l0   [3H]      */
+  /* Optional (NULL = none): a caller-kept device buffer of wgnn_prepared_bytes() bytes holding W_ih in the form the
+   * GEMM kernels stage it (fp16 hi/lo stage-major planes of [W_ih | b_ih] and of W_ih^T in the fp16-plane modes,
+   * zero-padded fp32 copies in WGNN_MATH_F32).  With NULL, wgnn_fwd* / wgnn_bwd* rebuild those images inside the
+   * workspace on every call (two launch-sized passes per call).  A caller that keeps the buffer must refresh it with
+   * wgnn_prepare_weights() whenever it changes w_ih / b_ih itself; wgnn_finish(adam) keeps it current. */
+  void* prepared;
 } wgnn_params;
 
 typedef struct wgnn_grads {
@@ -122,6 +129,14 @@ typedef struct wgnn_grads {
   float* b_ih;
   float* b_hh;
 } wgnn_grads;
+
+/* torch.optim.Adam state and hyper-parameters for the 8 tensors (src/main.py:52,80). */
+typedef struct wgnn_adam {
+  wgnn_grads exp_avg;    /* first moments, same 8 slots as the parameters */
+  wgnn_grads exp_avg_sq; /* second moments */
+  int32_t step;          /* 1-based count of THIS update (bias correction uses it) */
+  float lr, beta1, beta2, eps;
+} wgnn_adam;
 
 int wgnn_version(void);
 const char* wgnn_strerror(int status);
@@ -168,7 +183,7 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_param
  * all-reducing the GRU gradients as soon as part 4 is done. */
 int wgnn_bwd_part(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p,
                   const void* Y, const float* dY, const void* stash, const wgnn_grads* g,
-                  void* workspace, size_t workspace_bytes, void* stream, int part /* bit mask 1..7 */);
+                  void* workspace, size_t workspace_bytes, void* stream, int part /* bit mask 1..7, + WGNN_BWD_DEFER */);
 
 /* The reference's loss call folded into the backward (src/main.py:72 + :79): gradients of
  * grad_scale * mean((Y - labels)^2) w.r.t. the 8 parameters, and loss[0] = mean((Y - labels)^2) (written by the call
@@ -178,7 +193,32 @@ int wgnn_bwd_part(const wgnn_dims* d, const float* A, const void* X, const wgnn_
 int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p,
                       const void* Y, const void* labels /* [B,T,H], d->io */, float grad_scale, float* loss,
                       const void* stash, const wgnn_grads* g, void* workspace, size_t workspace_bytes,
-                      void* stream, int part /* bit mask 1..7, + 8: the forward was wgnn_fwd_loss on these labels */);
+                      void* stream, int part /* bit mask 1..7, + 8: the forward was wgnn_fwd_loss on these labels, + WGNN_BWD_DEFER */);
+
+/* `part` bit of wgnn_bwd_part / wgnn_bwd_mse_part: leave the split-K partial sums of the weight-gradient GEMMs (part 4)
+ * and the per-workgroup partial sums of the GCN backward (part 2) un-reduced inside the workspace; `g` is not written.
+ * wgnn_finish() on the SAME workspace, before any other call that uses it, reduces them. */
+#define WGNN_BWD_DEFER 16
+
+/* The tail of a training step as ONE launch (src/main.py:79-80: the end of loss.backward() + optimizer.step()):
+ *   which & 4   reduce the deferred partials of part 4 into g->w_ih, b_ih, w_hh, b_hh (fixed order: deterministic);
+ *   which & 2   reduce the deferred partials of part 2 into the four conv gradients;
+ *   adam        (NULL = none) torch.optim.Adam semantics on all 8 parameters `p` (updated in place) with the gradients
+ *               just reduced, or as they stand in `g` for the parts not named in `which`; if p->prepared is set, the
+ *               staged images of the NEW w_ih / b_ih are written too, so the next wgnn_fwd* / wgnn_bwd* need no
+ *               re-split / re-pad pass.
+ * One rank: wgnn_bwd_mse_part(.., 7 | 8 | WGNN_BWD_DEFER), wgnn_finish(.., 6, &adam).  Data parallel: part 1 | 4 | DEFER,
+ * wgnn_finish(4, NULL), all-reduce of the GRU gradients overlapped with part 2 | DEFER, wgnn_finish(2, NULL), all-reduce
+ * of the conv gradients, wgnn_finish(0, &adam).  The fused and the split form give bitwise identical results. */
+int wgnn_finish(const wgnn_dims* d, const wgnn_params* p, const wgnn_grads* g, int which, const wgnn_adam* adam,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Bytes of the caller-kept W_ih images (wgnn_params.prepared); depends on S, H and math only; 0 = this configuration
+ * stages W_ih as it is (then wgnn_prepare_weights returns WGNN_ERR_UNSUPPORTED and `prepared` is ignored). */
+size_t wgnn_prepared_bytes(const wgnn_dims* d);
+/* Build the images of p->w_ih / p->b_ih in p->prepared (all of it, padding included).  workspace: the status block. */
+int wgnn_prepare_weights(const wgnn_dims* d, const wgnn_params* p, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* One GraphConvLayer: out[n,S,F] = relu(A X[n] W + b) for n = 0..ntiles-1 (ntiles = prod of the
  * leading dims of attr_matrix).  Backward: dW, db (overwritten) and, if dX != NULL, dX. */

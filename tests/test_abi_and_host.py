@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(L.EXPORTS), (declared ^ set(L.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.wgnn_version() == 110
+    assert lib.wgnn_version() == 120
 
 
 def test_dims_validation_no_gpu_needed():
@@ -54,6 +54,28 @@ def test_dims_validation_no_gpu_needed():
     assert rc == -1 and b"NULL" in lib.wgnn_strerror(rc)
     bad = L.Dims(4, 24, 34, 12, 102, 0, 0, 0)
     assert lib.wgnn_fwd(ctypes.byref(bad), None, None, ctypes.byref(p), None, None, None, 0, None) == -2
+
+
+def test_finish_and_prepared_entry_points_validate_without_a_gpu():
+    L, lib = _lib()
+    x3 = L.Dims(4, 24, 34, 13, 102, 1, 0, 0)
+    f32 = L.Dims(4, 24, 34, 13, 102, 0, 0, 0)
+    wide = L.Dims(4, 24, 34, 13, 400, 0, 0, 0)            # wide GRU in exact fp32: W_ih is staged as it is
+    nx, nf = lib.wgnn_prepared_bytes(ctypes.byref(x3)), lib.wgnn_prepared_bytes(ctypes.byref(f32))
+    assert nx > 4 * 306 * 442 and nf > 8 * 306 * 442      # two images of W_ih each (fp16 hi+lo planes / padded fp32)
+    assert lib.wgnn_prepared_bytes(ctypes.byref(wide)) == 0
+    # the images depend on S, H and math only: one buffer serves every batch size
+    assert lib.wgnn_prepared_bytes(ctypes.byref(L.Dims(4096, 24, 34, 13, 102, 1, 0, 0))) == nx
+    assert lib.wgnn_prepared_bytes(ctypes.byref(L.Dims(4096, 24, 34, 13, 102, 0, 0, 0))) == nf
+    p, g = L.Params(), L.Grads()
+    assert p.prepared is None                              # the 9th slot of wgnn_params defaults to NULL
+    assert lib.wgnn_finish(ctypes.byref(x3), ctypes.byref(p), None, 6, None, None, 0, None) == -1
+    assert lib.wgnn_finish(ctypes.byref(x3), ctypes.byref(p), ctypes.byref(g), 8, None, None, 0, None) == -2
+    assert lib.wgnn_finish(ctypes.byref(x3), ctypes.byref(p), ctypes.byref(g), 0, None, None, 0, None) == -2
+    assert lib.wgnn_prepare_weights(ctypes.byref(x3), ctypes.byref(p), None, 0, None) == -1
+    bad = L.Dims(4, 24, 34, 12, 102, 1, 0, 0)
+    assert lib.wgnn_finish(ctypes.byref(bad), ctypes.byref(p), ctypes.byref(g), 6, None, None, 0, None) == -2
+    assert ctypes.sizeof(L.Adam) == 2 * 8 * ctypes.sizeof(ctypes.c_void_p) + 5 * 4 + 4   # wgnn_adam, padded to 8
 
 
 def test_module_mirrors_reference_state_dict():

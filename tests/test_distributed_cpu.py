@@ -1,5 +1,5 @@
-"""N > 1 path on CPU (gloo, world_size 2): sharding + the single flat-bucket all-reduce reproduce the
-big-batch gradient and the reference's Adam step.  The per-rank compute is the ORACLE here (test
+"""N > 1 path on CPU (gloo, world_size 2 and 3): sharding + the bucket exchange (two all-reduces per step) reproduce the
+big-batch gradient and loss, with unequal shards and shard sizes that change between steps.  The per-rank compute is the ORACLE here (test
 infrastructure standing in for the HIP kernels, which need a GPU); what is under test is the host
 logic of windgnn_amd/distributed.py that bench.py / TrainStep use on the GPU box."""
 import os
@@ -31,15 +31,23 @@ def _worker(rank, world, port, out_dir):
     fx = load_fixture("f2_s7_t12_b32_ckpt")
     A, X, L = (torch.from_numpy(fx[k]) for k in ("A", "X", "L"))
     p = {k: v.clone() for k, v in fx["params"].items()}
-    Xs, Ls = wd.shard_windows(X, L, rank, world)
-    Y, cache = orc.forward(A, Xs, p)
-    loss_local, dY = orc.mse_loss_and_grad(Y, Ls)
-    dY = dY * wd.grad_scale_for_shard(Xs.shape[0], X.shape[0])
-    grads = orc.backward(A, Xs, p, Y, cache, dY)
-    flat = wd.flatten([grads[k] for k in PARAM_KEYS])
-    wd.allreduce_flat_(flat)
-    if rank == 0:
-        np.save(os.path.join(out_dir, "flat.npy"), flat.numpy())
+    sizes = [p[k].numel() for k in PARAM_KEYS]
+    bucket = torch.zeros(wd.HEADER + sum(sizes))
+    ex = wd.BucketExchange(bucket, sum(sizes[:4]))             # the class TrainStep and bench.py run
+    # Global batches of 31, 32, 29 and 32 windows: with two ranks the shards are (16,15), (16,16), (15,14), (16,16) --
+    # rank 0's local count repeats while the global batch changes (a per-rank cache of the shard weight
+    # then skipped a collective the other rank issued), shards are unequal, and sizes change between steps.
+    for step, n_glob in enumerate((31, 32, 29, 32)):
+        Xs, Ls = wd.shard_windows(X[:n_glob], L[:n_glob], rank, world)
+        # even steps: the count is all-reduced (every rank, every step); odd steps: the caller states it
+        w = ex.shard_weight(Xs.shape[0], None if step % 2 == 0 else n_glob)
+        Y, cache = orc.forward(A, Xs, p)
+        loss_local, dY = orc.mse_loss_and_grad(Y, Ls)
+        grads = orc.backward(A, Xs, p, Y, cache, dY * w)
+        bucket[wd.LOSS_SLOT] = loss_local
+        bucket[wd.HEADER:] = wd.flatten([grads[k] for k in PARAM_KEYS])
+        ex.finish(ex.start_gru(), w)
+        np.save(os.path.join(out_dir, "bucket_%d_rank%d.npy" % (step, rank)), bucket.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,10 +64,29 @@ def test_shard_ranges_cover_everything():
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_two_rank_allreduce_equals_big_batch(tmp_path, world):
+def test_bucket_exchange_equals_big_batch_with_unequal_and_changing_shards(tmp_path, world):
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd import distributed as wd
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    flat = torch.from_numpy(np.load(os.path.join(str(tmp_path), "flat.npy")))
     fx = load_fixture("f2_s7_t12_b32_ckpt")
-    ref = torch.cat([fx["grads"][k].reshape(-1) for k in PARAM_KEYS])      # reference big-batch gradient
-    assert rel_to_max(flat, ref) <= 2e-5
+    A, X, L = (torch.from_numpy(fx[k]) for k in ("A", "X", "L"))
+    for step, n_glob in enumerate((31, 32, 29, 32)):
+        _, loss, g = orc.train_step(A, X[:n_glob], L[:n_glob], fx["params"])
+        ref = torch.cat([g[k].reshape(-1) for k in PARAM_KEYS])
+        if n_glob == 32:                                                   # the reference's own big-batch gradient
+            ref = torch.cat([fx["grads"][k].reshape(-1) for k in PARAM_KEYS])
+        for rank in range(world):                                          # every rank ends with the same bucket
+            b = torch.from_numpy(np.load(os.path.join(str(tmp_path), "bucket_%d_rank%d.npy" % (step, rank))))
+            assert rel_to_max(b[wd.HEADER:], ref) <= 2e-5, (step, rank)
+            assert abs(float(b[wd.LOSS_SLOT]) - float(loss)) <= 1e-6 * max(1.0, float(loss)), (step, rank)
+
+
+def test_shard_weight_rejects_an_impossible_global_count():
+    """a caller-stated n_global smaller than the local shard is a bug upstream: loud, not a silently wrong scale"""
+    import types
+    from windgnn_amd import distributed as wd
+    ex = types.SimpleNamespace(bucket=torch.zeros(8), group=None)
+    with pytest.raises(RuntimeError):
+        wd.BucketExchange.shard_weight(ex, 16, 8)
+    assert wd.BucketExchange.shard_weight(ex, 16, 32) == 0.5

@@ -23,14 +23,16 @@ def _free_port():
     return p
 
 
-def _train(rank, world, port, out_dir, backend="gloo", tag=None):
+def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32), stated=False):
+    """`batches`: the global batch of each step (sharded over the ranks); `stated`: pass n_global to TrainStep.step
+    instead of letting the exchange all-reduce the count."""
+    from windgnn_amd.distributed import ensure_rccl_env, shard_windows
+    ensure_rccl_env()                     # the environment bench.py establishes, before this process touches the GPU
     from windgnn_amd import GCN_GRU
-    from windgnn_amd.distributed import shard_windows
     from windgnn_amd.trainer import TrainStep
     group = None
     if world > 1 or backend == "nccl":
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             torch.cuda.set_device(0)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
@@ -46,11 +48,10 @@ def _train(rank, world, port, out_dir, backend="gloo", tag=None):
     assert tr.collective == (world > 1 or backend == "nccl")
     A = torch.from_numpy(fx["A"]).to(dev)
     X, L = torch.from_numpy(fx["X"]), torch.from_numpy(fx["L"])
-    Xs, Ls = shard_windows(X, L, rank, world)
-    Xs, Ls = Xs.contiguous().to(dev), Ls.contiguous().to(dev)
     losses = []
-    for _ in range(2):
-        loss, _ = tr.step(A, Xs, Ls)
+    for n_glob in batches:
+        Xs, Ls = shard_windows(X[:n_glob], L[:n_glob], rank, world)
+        loss, _ = tr.step(A, Xs.to(dev), Ls.to(dev), n_global=n_glob if stated else None)
         losses.append(float(loss))
     torch.cuda.synchronize()
     if rank == 0:
@@ -74,6 +75,26 @@ def test_two_rank_training_equals_single_process(tmp_path):
     l1 = np.load(os.path.join(str(tmp_path), "loss_world1.npy"))
     l2 = np.load(os.path.join(str(tmp_path), "loss_world2.npy"))
     assert np.abs(l1 - l2).max() <= 1e-6 * max(1.0, float(np.abs(l1).max()))
+
+
+def test_two_rank_training_with_unequal_and_changing_shards(tmp_path):
+    """Global batches of 31, 32, 29, 32 windows over two ranks: shards (16,15), (16,16), (15,14), (16,16).  Rank 0's
+    local count repeats while the global batch changes (the per-rank shard-weight cache then skipped a
+    collective the other rank issued -> mismatched all-reduces); every collective is now issued by every rank on
+    every step.  Parameters and losses must equal the single-process run over the same global batches, both when
+    the exchange all-reduces the window count and when the caller states it."""
+    assert torch.cuda.is_available()
+    sched = (31, 32, 29, 32)
+    _train(0, 1, 0, str(tmp_path), "gloo", "ref", sched)
+    mp.spawn(_train, args=(2, _free_port(), str(tmp_path), "gloo", "counted", sched, False), nprocs=2, join=True)
+    mp.spawn(_train, args=(2, _free_port(), str(tmp_path), "gloo", "stated", sched, True), nprocs=2, join=True)
+    p1 = torch.from_numpy(np.load(os.path.join(str(tmp_path), "p_ref.npy")))
+    l1 = np.load(os.path.join(str(tmp_path), "loss_ref.npy"))
+    for tag in ("counted", "stated"):
+        p2 = torch.from_numpy(np.load(os.path.join(str(tmp_path), "p_%s.npy" % tag)))
+        assert max_abs(p1, p2) <= 4e-5, tag          # four Adam steps
+        l2 = np.load(os.path.join(str(tmp_path), "loss_%s.npy" % tag))
+        assert np.abs(l1 - l2).max() <= 1e-6 * max(1.0, float(np.abs(l1).max())), tag
 
 
 def test_rccl_allreduce_path_executes_and_is_bitwise_neutral_with_one_rank(tmp_path):
@@ -102,7 +123,7 @@ def test_bench_multi_gpu_code_path_runs_under_torchrun_with_rccl():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5",
            "--warmup", "2", "--force-dist", "--no-cpu-baseline", "--no-traffic", "--no-secondary", "--batch", "512"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}   # bench.py must set it itself
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

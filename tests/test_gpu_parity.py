@@ -10,6 +10,9 @@ pytestmark = pytest.mark.gpu
 
 Y_TOL = 1e-4
 G_TOL = 1e-4
+# test_random_shape_sweep[f16] at 1x the one-pass-fp16 tolerance: (case, parameter) -> pinned bound of the known
+# outliers (tiny batches: S = 47, T = 2, B = 6, H = 10 averages the fp16 rounding of conv1.weight's gradient over 12 tiles)
+F16_SWEEP_EXCEPTIONS = {(12, "conv1.weight"): 5.5e-2}     # observed 5.07e-2 (r3, gpurun_out/c1)
 
 
 def _dev():
@@ -96,9 +99,10 @@ def test_random_shape_sweep(math):
     from oracle import windgnn_oracle as orc
     dev = _dev()
     rnd = random.Random(20260 + len(math))
-    # one-pass fp16: twice the golden-fixture gradient tolerance -- shapes with a handful of windows average less
-    # rounding noise than the fixtures do (worst case here: 5.1e-2 on conv1.weight at S = 47, T = 2, B = 6, H = 10)
-    y_tol, g_tol = (F16_Y_TOL, 2 * F16_G_TOL) if math == "f16" else (Y_TOL, G_TOL)
+    # one-pass fp16 runs at 1x the golden-fixture tolerances; shapes with a handful of windows average less rounding
+    # noise than the fixtures do, and the known worst cases are pinned one by one in F16_SWEEP_EXCEPTIONS
+    y_tol, g_tol = (F16_Y_TOL, F16_G_TOL) if math == "f16" else (Y_TOL, G_TOL)
+    seen = {}
     for case in range(24):
         S, T, B, H = rnd.randint(1, 64), rnd.randint(1, 9), rnd.randint(1, 48), rnd.randint(1, 128)
         g = torch.Generator().manual_seed(7000 + case)
@@ -112,7 +116,15 @@ def test_random_shape_sweep(math):
         tag = (case, S, T, B, H)
         assert max_abs(out.reshape(Yo.shape), Yo) <= y_tol, tag
         for k in PARAM_KEYS:
-            assert rel_to_max(grads[k], go[k]) <= g_tol, (tag, k)
+            e = rel_to_max(grads[k], go[k])
+            if e > g_tol:
+                seen[(case, k)] = e
+    if math != "f16":
+        assert not seen, seen
+    else:                                       # exactly the pinned exceptions, each within its own pinned bound
+        assert set(seen) <= set(F16_SWEEP_EXCEPTIONS), seen
+        for key, e in seen.items():
+            assert e <= F16_SWEEP_EXCEPTIONS[key], (key, e)
 
 
 def test_graph_conv_layer_module_with_input_grad():
@@ -641,8 +653,18 @@ def test_reference_training_loop_body_verbatim_through_the_dropin(fixture, math,
                     # formulas differ by 3.8e-5 on such elements of this fixture (|g| ~ 3e-9, max|g| = 0.35).
                     # Per element: 2e-5, plus the share of the step that rounding noise in g can redirect.
                     gref = torch.from_numpy(fx["g." + k]).double().abs()
-                    allow = 2e-5 + it * 1e-3 * torch.clamp(1e-6 * gref.max() / (gref + 1e-8), max=1.0)
                     err = (v.cpu().double() - torch.from_numpy(fx["a%d.%s" % (it, k)]).double()).abs()
+                    if math == "f32":
+                        # exact-fp32 mode (the module's default), no noise-aware allowance: EVERY element within 4e-5 of
+                        # the reference's own trajectory (the spread between the reference's fp32 run and an fp64
+                        # evaluation of the same formulas is 3.8e-5 on this fixture: an exact-fp32 kernel with another
+                        # summation order cannot be held tighter than that) and all but 0.1 % within 2e-5.
+                        # Observed (tools/tolerance_probe.py, r3): max 2.2e-5 / 2.9e-5 after 1 / 3 steps, ONE element of
+                        # W_ih beyond 2e-5, every other tensor <= 1.5e-5.
+                        assert float(err.max()) <= 4e-5, (it, k, float(err.max()))
+                        assert float((err > 2e-5).double().mean()) <= 1e-3, (it, k)
+                        continue
+                    allow = 2e-5 + it * 1e-3 * torch.clamp(1e-6 * gref.max() / (gref + 1e-8), max=1.0)
                     assert bool((err <= allow).all()), (it, k, float((err - allow).max()))
                     assert float((err > 2e-5).double().mean()) <= 0.05, (it, k)      # and almost all are within 2e-5
     with torch.no_grad():                                                                     # :100-102
@@ -974,9 +996,142 @@ def test_twenty_training_steps_track_the_fp64_oracle(math):
         assert abs(float(loss) - float(loss_o)) <= 1e-4 * max(1.0, float(loss_o)), (step, float(loss), float(loss_o))
     for k, v in model.named_parameters():
         # Adam's update lr * g / (|g| + 1e-8) is sign-like: on elements whose gradient is rounding noise it is not
-        # determined by the inputs (see the drop-in loop test; observed: 5 % of W_ih in f16x3, none in f32); 20 steps
+        # determined by the inputs (see the drop-in loop test; observed: 5 % of W_ih in f16x3, 0.7 % in f32); 20 steps
         # of lr = 1e-3 bound the effect at 2e-2, everything else stays within 1e-4 -- and the loss trajectory above,
         # which is what those elements cannot move, agrees at every step
         err = (v.detach().cpu().double() - p[k]).abs()
-        assert float((err > 1e-4).double().mean()) <= 0.10, k
-        assert float(err.max()) <= 2.5e-2, k
+        # observed (tools/tolerance_probe.py, r3): f32 max 3.1e-4 with 0.7 % of W_ih beyond 1e-4 and every other tensor
+        # <= 5.2e-5; f16x3 max 9.8e-4 with 3.5-6.4 % beyond 1e-4.  The bounds below are those observations with a 1.5-2x
+        # margin, per mode -- exact fp32 is NOT graded with f16x3's slack.
+        frac, worst = float((err > 1e-4).double().mean()), float(err.max())
+        if math == "f32":
+            assert worst <= 5e-4 and frac <= 0.012, (k, worst, frac)
+            if k != "gru.weight_ih_l0":
+                assert worst <= 1e-4, (k, worst)
+        else:
+            assert worst <= 2e-3 and frac <= 0.10, (k, worst, frac)
+
+
+def test_raw_entry_points_refuse_strided_tensors_and_trainstep_copies_them():
+    """the C ABI reads dense memory from data_ptr().  A strided batch slice handed to the raw entry
+    points must raise (not be read as if dense); TrainStep.step makes it contiguous itself and gives the result of the
+    dense copy bit for bit; the nn.Module path already copied."""
+    from windgnn_amd.functional import gcn_gru_backward_mse_raw, gcn_gru_forward_raw
+    from windgnn_amd.trainer import TrainStep
+    dev = _dev()
+    fx = load_fixture("f2b_s7_t12_b4_rand")
+    A = torch.from_numpy(fx["A"]).to(dev)
+    X2 = torch.from_numpy(fx["X"]).repeat_interleave(2, dim=0).to(dev)      # [8,...]: every window twice
+    L2 = torch.from_numpy(fx["L"]).repeat_interleave(2, dim=0).to(dev)
+    X2[1::2] += 1.0                                                          # the rows a dense read would pick up instead
+    Xs, Ls = X2[::2], L2[::2]
+    assert not Xs.is_contiguous()
+    model = _model_from(fx["params"], 7, 21, "f32")
+    params = list(model.hot_path_parameters())
+    with pytest.raises(RuntimeError, match="contiguous"):
+        gcn_gru_forward_raw(A, Xs, params, model.math)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        gcn_gru_forward_raw(A, Xs.contiguous(), params, model.math, labels=Ls)
+    Y, stash, d = gcn_gru_forward_raw(A, Xs.contiguous(), params, model.math, labels=Ls.contiguous())
+    grads = [torch.empty_like(q) for q in params]
+    loss = torch.zeros((), device=dev)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        gcn_gru_backward_mse_raw(d, A, Xs, params, Y, Ls.contiguous(), stash, grads, loss)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        gcn_gru_backward_mse_raw(d, A, Xs.contiguous(), params, Y, Ls, stash, grads, loss)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        gcn_gru_backward_mse_raw(d, A.t(), Xs.contiguous(), params, Y, Ls.contiguous(), stash, grads, loss)
+    # the module path and TrainStep copy: same numbers as the dense tensors
+    with torch.no_grad():
+        assert torch.equal(model(A, Xs), model(A, Xs.contiguous()))
+    assert max_abs(model(A, Xs).detach().cpu(), fx["Y"]) <= Y_TOL
+    t1 = TrainStep(_model_from(fx["params"], 7, 21, "f32"))
+    t2 = TrainStep(_model_from(fx["params"], 7, 21, "f32"))
+    l1, _ = t1.step(A, Xs, Ls)
+    l2, _ = t2.step(A, Xs.contiguous(), Ls.contiguous())
+    assert float(l1) == float(l2) and torch.equal(t1.flat_p, t2.flat_p)
+    assert abs(float(l1) - float(fx["loss"])) <= 1e-5
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("S,T,B,H,csr", [(34, 24, 256, 102, False), (7, 12, 32, 21, False), (5, 3, 17, 9, False),
+                                         (20, 4, 6, 200, False), (100, 3, 4, 60, True), (64, 2, 3, 127, False)])
+def test_finish_kernel_equals_the_separate_reduce_adam_and_prepare_passes(S, T, B, H, csr, math):
+    """wgnn_finish (one launch: deferred split-K / per-workgroup partial sums -> gradients, Adam, the staged W_ih images)
+    against the passes it replaces (tn_reduce / splitk_reduce x2, gcn_partial_reduce, wgnn_adam_step, wgnn_prepare_weights)
+    on the fast kernels (B*T >= 4096 included: the LDS-DMA fp32 GEMMs), the wide-GRU path and a CSR adjacency; and the
+    data-parallel split form (finish(4), finish(2), finish(0, adam)) against the fused one, bit for bit."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd import _lib
+    from windgnn_amd.functional import (adam_step_, finish_step, gcn_gru_backward_mse_raw, gcn_gru_forward_raw,
+                                        prepared_weights, refresh_prepared)
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    dev = _dev()
+    g = torch.Generator().manual_seed(31 * S + H)
+    if csr:
+        A = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=3), 6)).to(dev)
+    else:
+        A = (torch.rand(S, S, generator=g) / S + 0.01).to(dev)
+    X = torch.rand(B, T, S, 13, generator=g).to(dev)
+    L = torch.rand(B, T, H, generator=g).to(dev)
+    p0 = orc.init_params(S, 13, H, seed=S + H)
+    mode = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3, "f16": _lib.MATH_F16}[math]
+    hyper = dict(step=3, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8)
+
+    def fresh():
+        ps = [p0[k].clone().to(dev) for k in PARAM_KEYS]
+        gg = torch.Generator().manual_seed(5)
+        ms = [(torch.rand(q.shape, generator=gg) * 1e-3).to(dev) for q in ps]       # a mid-training optimiser state
+        vs = [(torch.rand(q.shape, generator=gg) * 1e-6).to(dev) for q in ps]
+        return ps, [torch.full_like(q, 7.0) for q in ps], ms, vs
+
+    # ---- reference: the separate passes
+    ps, gs, ms, vs = fresh()
+    loss = torch.zeros((), device=dev)
+    Y, stash, d = gcn_gru_forward_raw(A, X, ps, mode, labels=L)
+    gcn_gru_backward_mse_raw(d, A, X, ps, Y, L, stash, gs, loss, 1.0, part=7 | 8)
+    g_ref = [q.clone() for q in gs]
+    for q, gq, m, v in zip(ps, gs, ms, vs):
+        adam_step_(q, gq, m, v, hyper["step"], hyper["lr"], hyper["beta1"], hyper["beta2"], hyper["eps"])
+    img_ref = prepared_weights(d, ps, dev)
+    p_ref, m_ref, v_ref, loss_ref = ps, ms, vs, float(loss)
+
+    def run(split):
+        ps, gs, ms, vs = fresh()
+        img = prepared_weights(d, ps, dev)
+        loss = torch.zeros((), device=dev)
+        adam = dict(exp_avg=ms, exp_avg_sq=vs, **hyper)
+        Y, stash, d2 = gcn_gru_forward_raw(A, X, ps, mode, labels=L, prepared=img)
+        if split:
+            gcn_gru_backward_mse_raw(d2, A, X, ps, Y, L, stash, gs, loss, 1.0, part=1 | 4 | 8 | _lib.BWD_DEFER, prepared=img)
+            finish_step(d2, ps, gs, 4)
+            gcn_gru_backward_mse_raw(d2, A, X, ps, Y, L, stash, gs, loss, 1.0, part=2 | _lib.BWD_DEFER, prepared=img)
+            finish_step(d2, ps, gs, 2)
+            finish_step(d2, ps, gs, 0, adam, img)
+        else:
+            gcn_gru_backward_mse_raw(d2, A, X, ps, Y, L, stash, gs, loss, 1.0, part=7 | 8 | _lib.BWD_DEFER, prepared=img)
+            finish_step(d2, ps, gs, 6, adam, img)
+        return ps, gs, ms, vs, img, float(loss)
+
+    fused = run(False)
+    for k, a, b in zip(PARAM_KEYS, fused[1], g_ref):
+        if k.startswith("gru"):
+            assert torch.equal(a, b), k                      # same summation tree as tn_reduce / splitk_reduce
+        else:
+            assert rel_to_max(a.cpu(), b.cpu()) <= 2e-6, k   # the conv partial rows are summed in another (fixed) order
+    assert fused[5] == loss_ref
+    for k, a, b in zip(PARAM_KEYS, fused[0], p_ref):
+        assert max_abs(a.cpu(), b.cpu()) <= 2e-7, k          # Adam with explicit roundings vs the flat-buffer kernel
+    for a, b in zip(fused[2] + fused[3], m_ref + v_ref):
+        assert rel_to_max(a.cpu(), b.cpu()) <= 1e-6
+    if img_ref is not None:
+        # the images finish wrote must be exactly the images of the parameters finish wrote (padding included)
+        again = prepared_weights(d, fused[0], dev)
+        assert torch.equal(fused[4], again)
+        if math == "f32":
+            assert max_abs(fused[4].view(torch.float32).cpu(), img_ref.view(torch.float32).cpu()) <= 2e-7
+    split = run(True)
+    for a, b in zip(split[0] + split[1] + split[2] + split[3], fused[0] + fused[1] + fused[2] + fused[3]):
+        assert torch.equal(a, b)
+    assert (split[4] is None and fused[4] is None) or torch.equal(split[4], fused[4])
+    assert split[5] == fused[5]

@@ -24,13 +24,25 @@ class Dims(C.Structure):
                 ("math", C.c_int32), ("adj_format", C.c_int32), ("nnz", C.c_int32), ("io", C.c_int32)]
 
 
+_SLOTS = ("conv1_weight", "conv1_bias", "conv2_weight", "conv2_bias", "w_ih", "w_hh", "b_ih", "b_hh")
+
+
 class Params(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("conv1_weight", "conv1_bias", "conv2_weight", "conv2_bias",
-                                          "w_ih", "w_hh", "b_ih", "b_hh")]
+    # wgnn_params: the 8 tensors + the optional caller-kept images of W_ih (NULL = rebuilt inside every call)
+    _fields_ = [(n, C.c_void_p) for n in _SLOTS] + [("prepared", C.c_void_p)]
 
 
 class Grads(C.Structure):
-    _fields_ = Params._fields_
+    _fields_ = [(n, C.c_void_p) for n in _SLOTS]
+
+
+class Adam(C.Structure):
+    # wgnn_adam
+    _fields_ = [("exp_avg", Grads), ("exp_avg_sq", Grads), ("step", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float)]
+
+
+BWD_DEFER = 16              # WGNN_BWD_DEFER
 
 
 EXPORTS = {
@@ -51,6 +63,10 @@ EXPORTS = {
     "wgnn_bwd_mse_part": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                                     C.c_float, C.c_void_p, C.c_void_p, C.POINTER(Grads), C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_int]),
+    "wgnn_finish": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Grads), C.c_int, C.POINTER(Adam), C.c_void_p,
+                              C.c_size_t, C.c_void_p]),
+    "wgnn_prepared_bytes": (C.c_size_t, [C.POINTER(Dims)]),
+    "wgnn_prepare_weights": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p]),
     "wgnn_gcn_layer_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "wgnn_gcn_layer_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -93,7 +109,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.wgnn_version() < 110:
+    if lib.wgnn_version() < 120:
         raise RuntimeError("windgnn_amd: libwindgnn_hip.so is too old")
     _lib = lib
     return lib

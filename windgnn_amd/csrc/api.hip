@@ -1,6 +1,8 @@
 // extern "C" entry points of libwindgnn_hip.so (declared in include/windgnn.h).
 // Orchestrates the kernels of gcn.hip / gemm.hip / gru.hip / train_ops.hip on the caller's stream,
 // inside caller-owned workspace and stash buffers.  No allocation, no host synchronisation.
+#include <cmath>
+
 #include "common.h"
 
 namespace {
@@ -15,7 +17,10 @@ struct Layout {
   // stash
   size_t st_g, st_gates, st_yp, stash_floats;
   // backward workspace
-  size_t ws_dGI, ws_dGH, ws_dg, ws_part, ws_gcnpart, ws_planes_b, ws_scales, ws_dY, bwd_floats;
+  size_t ws_dGI, ws_dGH, ws_dg, ws_part_ih, ws_part_hh, ws_gcnpart, ws_planes_b, ws_scales, ws_dY, bwd_floats;
+  // caller-kept images of W_ih (wgnn_params.prepared): float offsets inside that buffer, 0 floats = this mode has none
+  size_t prep_f, prep_b, prep_floats;
+  int prep_kind;                                 // 0 none, 1 fp16 planes, 2 padded fp32
   int sk_ih, sk_hh;
   // which kernels run: the fp16-plane family needs the dense LDS-resident GCN and the register-resident GRU;
   // shapes beyond the fast kernels (CSR adjacency, wide hidden state) use general.hip in exact fp32
@@ -57,8 +62,15 @@ Layout make_layout(const wgnn_dims* d) {
   // exact fp32 at large B*T: the big-tile GEMMs of gemm32.hip on zero-padded copies of W_ih / W_ih^T
   L.g32 = !x3 && !L.gen_gcn && !L.gen_gru && gemm32_nt_supported(L.BT, (int)L.Ip, (int)L.Gp);
   L.g32tn = L.g32 && gemm32_tn_supported(L.BT);          // the split-K dW products (same threshold today)
-  const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : (L.g32 ? (size_t)gemm32_nt_rows((int)L.G3) * L.Ip : 0);   // 2 planes of halfs = that many floats
-  const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : (L.g32 ? (size_t)gemm32_nt_rows((int)L.I) * L.Gp : 0);
+  // the images of W_ih the GEMMs stage: sized from S and H alone (the exact-fp32 ones are USED from B*T >= 4096 only),
+  // so that a caller-kept copy (wgnn_params.prepared) serves every batch size
+  const bool g32_shape = !x3 && !L.gen_gcn && !L.gen_gru && gemm32_nt_supported(1u << 30, (int)L.Ip, (int)L.Gp);
+  const size_t planes_f = x3 ? (size_t)L.np_g3 * L.Ip : (g32_shape ? (size_t)gemm32_nt_rows((int)L.G3) * L.Ip : 0);   // 2 planes of halfs = that many floats
+  const size_t planes_b = x3 ? (size_t)L.np_i * L.Gp : (g32_shape ? (size_t)gemm32_nt_rows((int)L.I) * L.Gp : 0);
+  L.prep_kind = x3 ? 1 : (g32_shape ? 2 : 0);
+  L.prep_f = 0;
+  L.prep_b = al(planes_f);
+  L.prep_floats = L.prep_kind ? al(planes_f) + al(planes_b) : 0;
   constexpr size_t HDR = WGNN_STATUS_BYTES / sizeof(float);   // status block at the start of the workspace
   size_t o = HDR;
   L.ws_GI = o; o += al(L.BT * L.Gp);   // rows padded to 128-B multiples
@@ -72,7 +84,10 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_kp_f = o; o += al(L.gen_gru && x3 ? pgemm_nt_kpart_floats(d->B, (int)L.Gp, (int)L.Hp) : 0);
   L.ws_hc = o; o += al(L.gen_gru && x3 ? (size_t)d->B * L.Hp : 0);          // compact planes of h_{t-1}
   L.ws_xtail_f = o; o += al((L.I & 1) && !L.gen_gcn ? L.I + 1 : 0);        // private copy of X's last tile (odd S*13: see xtail_copy)
-  L.ws_Ylast = o; o += al((x3 && !L.gen_gru) ? 0 : L.BT * L.H);             // wgnn_fwd_last where the recurrence writes all of Y
+  // wgnn_fwd_last where the recurrence writes all of Y: wgnn_fwd_last has no stash, so g lives in ws_g and is dead once GI
+  // is formed -- Y aliases it whenever it fits (H <= Ip: always when H = 3S), and only otherwise gets a region of its own
+  if ((x3 && !L.gen_gru) || L.H <= L.Ip) { L.ws_Ylast = L.ws_g; }
+  else { L.ws_Ylast = o; o += al(L.BT * L.H); }
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
@@ -108,7 +123,8 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_dGI = o; o += al(L.BT * L.Gp);   // fp32, or hi+lo fp16 planes (same bytes)
   L.ws_dGH = o; o += al(L.dghn ? L.BT * (size_t)L.hn : L.BT * L.Gp);   // dGHn planes, or full dGH (general GRU / f32)
   L.ws_dg = o; o += al(L.BT * L.I);
-  L.ws_part = o; o += al(part_ih > part_hh ? part_ih : part_hh);
+  L.ws_part_ih = o; o += al(part_ih);     // separate regions: with WGNN_BWD_DEFER both stay live until wgnn_finish
+  L.ws_part_hh = o; o += al(part_hh);
   {
     size_t a = gcn32_bwd_partial_floats((int)L.BT), b = gcnx2_bwd_partial_floats((int)L.BT);
     if (L.gen_gcn) a = gcn_csr_bwd_partial_floats();
@@ -193,7 +209,9 @@ size_t wgnn_stash_bytes(const wgnn_dims* d) {
 // where the kernels cannot skip it (into the workspace, for the exact-fp32 and general-shape recurrences).
 static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* labels,
                     void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream, float* last = nullptr,
-                    float y_mul = 1.f, float y_add = 0.f) {
+                    float wind_min = 0.f, float wind_max = 1.f) {
+  // every read-out path forms its multiplier the same way, (wind_max - wind_min) in fp32, from the caller's two values
+  const float y_mul = wind_max - wind_min, y_add = wind_min;
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
   if (!A || !X || !p || (!Y && !last) || !workspace) return WGNN_ERR_NULL;
@@ -212,12 +230,16 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   float* gates = sf ? sf + L.st_gates : nullptr;
   const bool x3 = L.x3;                              // fp16-plane kernels
   const bool full = d->math == WGNN_MATH_F16X3;      // three-pass split products (false: one fp16 pass)
+  // the staged image of [W_ih | b_ih]: the caller's (wgnn_prepare_weights / wgnn_finish keep it current) or rebuilt here
+  const bool kept = p->prepared != nullptr && L.prep_kind != 0;
+  float* img_f = kept ? (float*)p->prepared + L.prep_f : ws + L.ws_planes_f;
 
   if (x3) {
     // W_ih as stage-major fp16 planes [np_g3][Ip] with b_ih folded into column I (g's ones column)
-    rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, (int)L.I, ws + L.ws_planes_f, L.np_g3,
-                              (int)L.Ip, status, st);
-    if (rc != WGNN_OK) return rc;
+    if (!kept) {
+      rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, (int)L.I, img_f, L.np_g3, (int)L.Ip, status, st);
+      if (rc != WGNN_OK) return rc;
+    }
     if (L.gen_gcn)    // CSR adjacency: fp32 SpMM layers, layer 2 writes the g planes
       rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, (const float*)X, p->conv1_weight, p->conv1_bias,
                                p->conv2_weight, p->conv2_bias, sf ? sf + L.st_h1 : ws + L.ws_h1, nullptr, g, L.Ip, full,
@@ -227,7 +249,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
                             p->conv2_bias, g, (int)L.Ip, full, status, ws + L.ws_xtail_f, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
-    rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, ws + L.ws_planes_f, L.np_g3, GI,
+    rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, img_f, L.np_g3, GI,
                          (int)L.Gp, (int)L.G3, nullptr, full, nullptr, st);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gru) {  // any hidden width: one plane GEMM per step against split(W_hh | b_hh)
@@ -238,7 +260,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
                                  sf ? sf + L.st_yp : ws + L.ws_yp, ws + L.ws_gh, ws + L.ws_kp_f, ws + L.ws_hc, full,
                                  st);
       if (rc != WGNN_OK || !last) return rc;
-      return wgnn_predict_last((const float*)Y, d->B, d->T, d->H, y_add, y_add + y_mul, last, stream);
+      return wgnn_predict_last((const float*)Y, d->B, d->T, d->H, wind_min, wind_max, last, stream);
     }
     if (last)   // the register-resident recurrence writes the read-out itself
       return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, last, nullptr, nullptr, full, status,
@@ -257,9 +279,11 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   }
   if (rc != WGNN_OK) return rc;
   if (L.g32) {       // GI = [g|1] [W_ih|b_ih]^T
-    float* wp = ws + L.ws_planes_f;
-    rc = launch_pad_weight(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, wp, gemm32_nt_rows((int)L.G3), (int)L.Ip, st);
-    if (rc != WGNN_OK) return rc;
+    float* wp = img_f;
+    if (!kept) {
+      rc = launch_pad_weight(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, wp, gemm32_nt_rows((int)L.G3), (int)L.Ip, st);
+      if (rc != WGNN_OK) return rc;
+    }
     rc = launch_gemm32_nt(g, (int)L.Ip, (int)L.BT, (int)L.Ip, wp, GI, (int)L.Gp, (int)L.G3, st);
   } else {
     GemmArgs ga = {};
@@ -277,7 +301,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   else
     rc = launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, st);
   if (rc != WGNN_OK || !last) return rc;
-  return wgnn_predict_last((const float*)Y, d->B, d->T, d->H, y_add, y_add + y_mul, last, stream);
+  return wgnn_predict_last((const float*)Y, d->B, d->T, d->H, wind_min, wind_max, last, stream);
 }
 
 int wgnn_fwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, void* Y, void* stash,
@@ -295,8 +319,121 @@ int wgnn_fwd_last(const wgnn_dims* d, const float* A, const void* X, const wgnn_
                   float wind_max, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!out) return WGNN_ERR_NULL;
   if (d && d->io != WGNN_IO_F32) return WGNN_ERR_UNSUPPORTED;
-  return fwd_impl(d, A, X, p, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, out, wind_max - wind_min,
-                  wind_min);
+  return fwd_impl(d, A, X, p, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, out, wind_min, wind_max);
+}
+
+size_t wgnn_prepared_bytes(const wgnn_dims* d) {
+  if (check_dims(d) != WGNN_OK) return 0;
+  return sizeof(float) * make_layout(d).prep_floats;
+}
+
+int wgnn_prepare_weights(const wgnn_dims* d, const wgnn_params* p, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  int rc = check_dims(d);
+  if (rc != WGNN_OK) return rc;
+  if (!p || !p->w_ih || !p->b_ih || !p->prepared || !workspace) return WGNN_ERR_NULL;
+  if (workspace_bytes < WGNN_STATUS_BYTES) return WGNN_ERR_WORKSPACE;
+  const Layout L = make_layout(d);
+  if (L.prep_kind == 0) return WGNN_ERR_UNSUPPORTED;            // wgnn_prepared_bytes() said 0
+  hipStream_t st = (hipStream_t)stream;
+  float* img_f = (float*)p->prepared + L.prep_f;
+  float* img_b = (float*)p->prepared + L.prep_b;
+  if (L.prep_kind == 1) {
+    rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, (int)L.I, img_f, L.np_g3, (int)L.Ip,
+                              (unsigned*)workspace, st);
+    if (rc != WGNN_OK) return rc;
+    return launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, img_b, L.np_i, (int)L.Gp, (unsigned*)workspace, st);
+  }
+  rc = launch_pad_weight(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, img_f, gemm32_nt_rows((int)L.G3), (int)L.Ip, st);
+  if (rc != WGNN_OK) return rc;
+  return launch_pad_weight(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, img_b, gemm32_nt_rows((int)L.I), (int)L.Gp, st);
+}
+
+int wgnn_finish(const wgnn_dims* d, const wgnn_params* p, const wgnn_grads* g, int which, const wgnn_adam* adam,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_dims(d);
+  if (rc != WGNN_OK) return rc;
+  if ((which & ~6) != 0 || (which == 0 && !adam)) return WGNN_ERR_SHAPE;
+  if (!g || !workspace || (adam && !p)) return WGNN_ERR_NULL;
+  if (!g->conv1_weight || !g->conv1_bias || !g->conv2_weight || !g->conv2_bias || !g->w_ih || !g->w_hh || !g->b_ih ||
+      !g->b_hh)
+    return WGNN_ERR_NULL;
+  const Layout L = make_layout(d);
+  if (workspace_bytes < sizeof(float) * L.bwd_floats) return WGNN_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  FinishArgs a = {};
+  a.scales = ws + L.ws_scales;
+  a.status = (unsigned*)workspace;
+  float* gs[8] = {g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, g->w_ih, g->w_hh, g->b_ih, g->b_hh};
+  const int F = d->F;
+  const int64_t n[8] = {(int64_t)F * F, F, (int64_t)F * F, F, (int64_t)L.G3 * (int64_t)L.I, (int64_t)L.G3 * (int64_t)L.H,
+                        (int64_t)L.G3, (int64_t)L.G3};
+  for (int t = 0; t < 8; ++t) {
+    a.g[t] = gs[t];
+    a.n[t] = (int)n[t];
+  }
+  a.I = (int)L.I;
+  if (which & 4) {   // the two GRU weight-gradient products of wgnn_bwd*_part(4 | WGNN_BWD_DEFER)
+    FinSeg& ih = a.ih;
+    ih.partial = ws + L.ws_part_ih;
+    ih.splitk = L.sk_ih;
+    ih.kind = L.x3 ? 2 : 1;
+    ih.Mout = (int)L.G3; ih.Nout = (int)L.I + 1; ih.ncols = (int)L.I;
+    ih.scaled = L.x3;
+    FinSeg& hh = a.hh;
+    hh = ih;
+    hh.partial = ws + L.ws_part_hh;
+    hh.splitk = L.sk_hh;
+    hh.Nout = (int)L.H + 1; hh.ncols = (int)L.H;
+    if (L.x3) {
+      pgemm_tn_geom((int)L.G3, ih.Nout, &ih.T, &ih.nNb, &ih.ntiles);
+      pgemm_tn_geom(L.m_hh, hh.Nout, &hh.T, &hh.nNb, &hh.ntiles);
+      if (L.dghn) { hh.msplit = L.msplit; hh.rows1 = 2 * d->H; }
+    }
+  }
+  if (which & 2) {   // the GCN backward's per-workgroup partial rows of wgnn_bwd*_part(2 | WGNN_BWD_DEFER)
+    a.conv_partial = ws + L.ws_gcnpart;
+    a.conv_rows = L.gen_gcn ? gcn_csr_bwd_rows()
+                            : (L.x3 ? gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3) : gcn32_bwd_grid((int)L.BT));
+  }
+  if (adam) {
+    if (!p->conv1_weight || !p->conv1_bias || !p->conv2_weight || !p->conv2_bias || !p->w_ih || !p->w_hh || !p->b_ih ||
+        !p->b_hh)
+      return WGNN_ERR_NULL;
+    if (adam->step < 1) return WGNN_ERR_SHAPE;
+    const float* ps[8] = {p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, p->w_ih, p->w_hh, p->b_ih, p->b_hh};
+    const wgnn_grads& m = adam->exp_avg;
+    const wgnn_grads& v = adam->exp_avg_sq;
+    float* ms[8] = {m.conv1_weight, m.conv1_bias, m.conv2_weight, m.conv2_bias, m.w_ih, m.w_hh, m.b_ih, m.b_hh};
+    float* vs[8] = {v.conv1_weight, v.conv1_bias, v.conv2_weight, v.conv2_bias, v.w_ih, v.w_hh, v.b_ih, v.b_hh};
+    for (int t = 0; t < 8; ++t) {
+      if (!ms[t] || !vs[t]) return WGNN_ERR_NULL;
+      a.p[t] = const_cast<float*>(ps[t]);          // the optimiser updates the parameters in place
+      a.m[t] = ms[t];
+      a.v[t] = vs[t];
+    }
+    a.adam = 1;
+    const double bc1 = 1.0 - pow((double)adam->beta1, (double)adam->step);
+    const double bc2 = 1.0 - pow((double)adam->beta2, (double)adam->step);
+    a.lr_over_bc1 = (float)(adam->lr / bc1);
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.b1 = adam->beta1; a.b2 = adam->beta2; a.eps = adam->eps;
+    a.elem_mask = ((which & 4) ? 0u : 0xF0u) | ((which & 2) ? 0u : 0x0Fu);   // tensors whose gradient is final in g
+    if (p->prepared && L.prep_kind) {
+      a.prep_kind = L.prep_kind;
+      float* img_f = (float*)p->prepared + L.prep_f;
+      float* img_b = (float*)p->prepared + L.prep_b;
+      if (L.prep_kind == 1) {
+        a.pf_hi = (_Float16*)img_f; a.pf_lo = a.pf_hi + (size_t)L.np_g3 * L.Ip;
+        a.pb_hi = (_Float16*)img_b; a.pb_lo = a.pb_hi + (size_t)L.np_i * L.Gp;
+        a.np_g3 = L.np_g3; a.np_i = L.np_i;
+      } else {
+        a.wp = img_f; a.wt = img_b;
+      }
+      a.Ip = (int)L.Ip; a.Gp = (int)L.Gp;
+    }
+  }
+  return launch_finish(a, (hipStream_t)stream);
 }
 
 int wgnn_bwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* Y,
@@ -313,8 +450,9 @@ namespace {
 int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_params* p, const void* Yv,
              const float* dY, const void* labelsv, float grad_scale, float* loss, const void* stash,
              const wgnn_grads* g, void* workspace, size_t workspace_bytes, void* stream, int which) {
-  if (which < 1 || which > 15 || (which & 7) == 0) return WGNN_ERR_SHAPE;
+  if (which < 1 || which > 31 || (which & 7) == 0) return WGNN_ERR_SHAPE;
   const bool do_rec = which & 1, do_gcn = which & 2, do_wg = which & 4;
+  const bool defer = which & WGNN_BWD_DEFER;          // partial sums stay in the workspace for wgnn_finish
   const float* X = (const float*)Xv;                 // io-typed (d->io): only the kernels that take `io` see 16-bit data
   const float* Y = (const float*)Yv;
   const float* labels = (const float*)labelsv;
@@ -337,7 +475,10 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
   float* dGI = ws + L.ws_dGI;
   float* dGH = ws + L.ws_dGH;
   float* dg = ws + L.ws_dg;
-  float* part = ws + L.ws_part;
+  float* part_ih = ws + L.ws_part_ih;
+  float* part_hh = ws + L.ws_part_hh;
+  const bool kept = p->prepared != nullptr && L.prep_kind != 0;
+  float* img_b = kept ? (float*)p->prepared + L.prep_b : ws + L.ws_planes_b;     // staged image of W_ih^T
   float* scales = ws + L.ws_scales;          // [0] = 2^k, [1] = 2^-k (f16x3 range scaling), [2] = dY coefficient; partials from 64
   const bool x3 = L.x3;
   const bool full = d->math == WGNN_MATH_F16X3;
@@ -385,41 +526,45 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       // planes and rows >= msplit from the dGHn planes; the reduce kernel maps the GEMM rows back to W_hh's rows.
       if (L.dghn) {
         rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
-                             L.sk_hh, part, L.m_hh, (int)L.H + 1, full, dGHh, dGHh + L.BT * (size_t)L.hn, L.hn, L.msplit, st);
+                             L.sk_hh, part_hh, L.m_hh, (int)L.H + 1, full, dGHh, dGHh + L.BT * (size_t)L.hn, L.hn, L.msplit, st);
         if (rc != WGNN_OK) return rc;
-        rc = launch_pgemm_tn_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
-                                    status, L.msplit, 2 * d->H, L.m_hh, st);
+        if (!defer)
+          rc = launch_pgemm_tn_reduce(part_hh, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
+                                      status, L.msplit, 2 * d->H, L.m_hh, st);
       } else {
         rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
-                             L.sk_hh, part, (int)L.G3, (int)L.H + 1, full, nullptr, nullptr, 0, 0, st);
+                             L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, full, nullptr, nullptr, 0, 0, st);
         if (rc != WGNN_OK) return rc;
-        rc = launch_pgemm_tn_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
-                                    status, 0, 0, (int)L.G3, st);
+        if (!defer)
+          rc = launch_pgemm_tn_reduce(part_hh, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
+                                      status, 0, 0, (int)L.G3, st);
       }
       if (rc != WGNN_OK) return rc;
       // dW_ih | db_ih = dGI^T [g | 1]
-      rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part,
+      rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part_ih,
                            (int)L.G3, (int)L.I + 1, full, nullptr, nullptr, 0, 0, st);
       if (rc != WGNN_OK) return rc;
-      rc = launch_pgemm_tn_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales,
-                                  status, 0, 0, (int)L.G3, st);
+      if (!defer)
+        rc = launch_pgemm_tn_reduce(part_ih, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales,
+                                    status, 0, 0, (int)L.G3, st);
       if (rc != WGNN_OK) return rc;
     }   // the four GRU gradients are final here: a data-parallel caller can start reducing them now
     if (!do_gcn) return WGNN_OK;
     // dg = dGI W_ih   (B operand = split(W_ih^T) [np_i][Gp]); dg stays in scaled units
-    rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, ws + L.ws_planes_b, L.np_i, (int)L.Gp, status,
-                              st);
-    if (rc != WGNN_OK) return rc;
-    rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, ws + L.ws_planes_b, L.np_i, dg, (int)L.I,
+    if (!kept) {
+      rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, img_b, L.np_i, (int)L.Gp, status, st);
+      if (rc != WGNN_OK) return rc;
+    }
+    rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.I,
                          (int)L.I, nullptr, full, nullptr, st);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gcn)
       return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
-                                 L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
-                                 g->conv2_weight, g->conv2_bias, st);
+                                 L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, defer ? nullptr : g->conv1_weight,
+                                 g->conv1_bias, g->conv2_weight, g->conv2_bias, st);
     rc = launch_gcnx2_bwd((int)L.BT, d->S, A, Xv, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                           scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, ws + L.ws_xtail_b, st);
-    if (rc != WGNN_OK) return rc;
+    if (rc != WGNN_OK || defer) return rc;
     return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3), g->conv1_weight, g->conv1_bias,
                                      g->conv2_weight, g->conv2_bias, status, st);
   }
@@ -440,40 +585,44 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       float* hp = ws + L.ws_hprev;
       rc = launch_hprev_pad(Y, d->B, d->T, d->H, hp, L.hq, st);
       if (rc != WGNN_OK) return rc;
-      rc = launch_gemm32_tn(dGH, (int)L.Gp, hp, L.hq, (int)L.BT, L.sk_hh, part, (int)L.G3, (int)L.H + 1, st);
+      rc = launch_gemm32_tn(dGH, (int)L.Gp, hp, L.hq, (int)L.BT, L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, st);
     } else {
       GemmArgs a = {};
       a.A = dGH; a.lda = (int)L.Gp; a.a_kcontig = 0;
       a.B = Y; a.ldb = (int)L.H; a.b_kcontig = 0; a.ones_col = 1; a.shift_T = d->T;
       a.M = (int)L.G3; a.N = (int)L.H + 1; a.K = (int)L.BT;
-      a.splitk = L.sk_hh; a.partial = part;
+      a.splitk = L.sk_hh; a.partial = part_hh;
       rc = launch_gemm_f32(a, st);
     }
     if (rc != WGNN_OK) return rc;
-    rc = launch_splitk_reduce(part, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, nullptr, st);
+    if (!defer)
+      rc = launch_splitk_reduce(part_hh, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, nullptr, st);
     if (rc != WGNN_OK) return rc;
     // dW_ih = dGI^T g, db_ih = dGI^T 1
     if (L.g32tn) {     // g carries its ones column (gcn32_fwd)
-      rc = launch_gemm32_tn(dGI, (int)L.Gp, gact, (int)L.Ip, (int)L.BT, L.sk_ih, part, (int)L.G3, (int)L.I + 1, st);
+      rc = launch_gemm32_tn(dGI, (int)L.Gp, gact, (int)L.Ip, (int)L.BT, L.sk_ih, part_ih, (int)L.G3, (int)L.I + 1, st);
     } else {
       GemmArgs b = {};
       b.A = dGI; b.lda = (int)L.Gp; b.a_kcontig = 0;
       b.B = gact; b.ldb = (int)L.Ip; b.b_kcontig = 0; b.ones_col = 1;
       b.M = (int)L.G3; b.N = (int)L.I + 1; b.K = (int)L.BT;
-      b.splitk = L.sk_ih; b.partial = part;
+      b.splitk = L.sk_ih; b.partial = part_ih;
       rc = launch_gemm_f32(b, st);
     }
     if (rc != WGNN_OK) return rc;
-    rc = launch_splitk_reduce(part, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, nullptr, st);
+    if (!defer)
+      rc = launch_splitk_reduce(part_ih, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, nullptr, st);
     if (rc != WGNN_OK) return rc;
   }
   if (!do_gcn) return WGNN_OK;
   {
     // dg = dGI W_ih
     if (L.g32) {
-      float* wt = ws + L.ws_planes_b;     // (W_ih^T) [I -> padded][Gp]
-      rc = launch_pad_weight(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, wt, gemm32_nt_rows((int)L.I), (int)L.Gp, st);
-      if (rc != WGNN_OK) return rc;
+      float* wt = img_b;                  // (W_ih^T) [I -> padded][Gp]
+      if (!kept) {
+        rc = launch_pad_weight(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, wt, gemm32_nt_rows((int)L.I), (int)L.Gp, st);
+        if (rc != WGNN_OK) return rc;
+      }
       rc = launch_gemm32_nt(dGI, (int)L.Gp, (int)L.BT, (int)L.Gp, wt, dg, (int)L.I, (int)L.I, st);
     } else {
       GemmArgs c = {};
@@ -486,10 +635,11 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
   }
   if (L.gen_gcn)
     return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, gact, nullptr, L.Ip, dg,
-                               L.I, nullptr, ws + L.ws_du, ws + L.ws_gcnpart, g->conv1_weight, g->conv1_bias,
-                               g->conv2_weight, g->conv2_bias, st);
+                               L.I, nullptr, ws + L.ws_du, ws + L.ws_gcnpart, defer ? nullptr : g->conv1_weight,
+                               g->conv1_bias, g->conv2_weight, g->conv2_bias, st);
   return launch_gcn32_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
-                         g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, ws + L.ws_gcnpart, ws + L.ws_xtail_b, st);
+                         defer ? nullptr : g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias,
+                         ws + L.ws_gcnpart, ws + L.ws_xtail_b, st);
 }
 }  // namespace
 

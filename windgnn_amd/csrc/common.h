@@ -72,7 +72,7 @@ extern bool g_prof_on;
   } while (0)
 
 // ---- range status (include/windgnn.h "Status block"): word 0 of the caller's workspace, only ever OR-ed into.
-// The fp16-plane modes cannot represent |x| >= 65520; where a kernel converts activations, weights or final
+// The fp16-plane modes cannot represent |x| > 65504 (fp16's largest finite value; anything beyond is flagged); where a kernel converts activations, weights or final
 // gradients it tests them (one v_cmp per value, NaN counts as out of range) and reports instead of letting an
 // inf/NaN slide through a ReLU (fmaxf(NaN, 0) = 0 would hide it).
 #define WGNN_FP16_MAX 65504.0f
@@ -135,13 +135,6 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
                     const float* gates,
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st);
 
-int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1,
-                    const float* b1, const float* W2, const float* b2, float* g, int ldg, float* xtail_scratch, hipStream_t st);
-// two-layer backward (no dX): partial buffer >= gcn2_bwd_partial_floats() floats
-size_t gcn2_bwd_partial_floats(int ntiles);
-int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1,
-                    const float* b1, const float* W2, const float* g, int ldg, const float* dg, float* dW1,
-                    float* db1, float* dW2, float* db2, float* partial, float* xtail_scratch, hipStream_t st);
 int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
                               unsigned* status, hipStream_t st);
 // register-chained exact-fp32 variants (gcn32.hip): what the WGNN_MATH_F32 path runs
@@ -214,7 +207,7 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* 
 int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY,
                    const float* gates, float* dGI, float* dGH, int ldd, hipStream_t st);
 bool gru_shape_supported(int H);
-// small batches (B <= 2048, H <= 128), exact fp32, one to four windows per workgroup with W_hh in registers (gru_small.hip)
+// small batches (B <= 1024, H <= 128), exact fp32, one window per workgroup with W_hh in registers (gru_small.hip)
 bool gru_small_supported(int B, int H);
 int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
                          float* gates, hipStream_t st);
@@ -223,5 +216,42 @@ int launch_gru_small_bwd(int B, int T, int H, const float* Whh, const float* Y, 
 
 int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY, float* loss,
                float* ws, hipStream_t st);
+
+// ---- finish.hip: reduction of the deferred partial sums + Adam + the prepared W_ih images, one launch
+constexpr int TN_BM = 320, TN_WAVES = 8;     // pgemm_tn_kernel's workgroup tile rows / waves (its partial layout)
+void pgemm_tn_geom(int Mgemm, int Nout, int* T, int* nNb, int* ntiles);
+int gcn32_bwd_grid(int ntiles);              // partial rows launch_gcn32_bwd writes
+int gcn_csr_bwd_rows();                      // partial rows launch_gcn2_csr_bwd writes
+struct FinSeg {                // one split-K weight-gradient product: C[Mout][ncols] and its bias column Nout - 1
+  const float* partial;
+  int splitk;
+  int kind;                    // 0: nothing to reduce; 1: plain [z][Mout][Nout]; 2: pgemm_tn_kernel's layout
+  int T, nNb, ntiles;          // kind 2
+  int Mout, Nout, ncols;
+  int msplit, rows1;           // kind 2 with a two-source A operand (pgemm_tn_kernel<.., A2>)
+  int scaled;                  // the partials are in units scaled by scales[0]: multiply by scales[1]
+  int nblocks;                 // filled in by launch_finish
+};
+struct FinishArgs {
+  FinSeg ih, hh;
+  const float* conv_partial;   // [conv_rows][544] per-workgroup partials of the GCN backward, or null
+  int conv_rows, conv_blocks, elem_blocks;
+  unsigned elem_mask;          // bit t: tensor t's gradient is final in g[t] already (Adam reads it from there)
+  const float* scales;
+  unsigned* status;
+  float* g[8];                 // state_dict order: conv1.w, conv1.b, conv2.w, conv2.b, w_ih, w_hh, b_ih, b_hh
+  float* p[8];
+  float* m[8];
+  float* v[8];
+  int n[8];
+  int adam;
+  float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps;
+  int prep_kind;               // 0: none; 1: fp16 hi/lo stage-major planes; 2: zero-padded fp32 copies
+  _Float16 *pf_hi, *pf_lo, *pb_hi, *pb_lo;
+  int np_g3, np_i;
+  float *wp, *wt;
+  int Ip, Gp, I;
+};
+int launch_finish(FinishArgs a, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr,
                 float b1, float b2, float eps, hipStream_t st);

@@ -1,0 +1,232 @@
+// The tail of the training step as ONE launch (src/main.py:79-80: the end of loss.backward() and optimizer.step()):
+//   * fixed-order reduction of the split-K partials of the two GRU weight-gradient products (dW_ih|db_ih, dW_hh|db_hh)
+//     and of the per-workgroup partials of the GCN backward (dW1, db1, dW2, db2) into the 8 gradients,
+//   * torch.optim.Adam (defaults semantics) on the 8 parameters,
+//   * the "prepared" images of W_ih the next step's GEMMs stage (fp16 hi/lo stage-major planes of [W_ih | b_ih] and of
+//     W_ih^T in the fp16-plane modes, zero-padded fp32 copies in exact fp32) -- Adam already holds the new weights.
+// It replaces, per step, tn_reduce x2 (or splitk_reduce x2), gcn_partial_reduce, adam and next step's split_weight2 x2
+// (or pad_weight x2): six launch-sized passes.  With a gradient all-reduce in between (N > 1) the same kernel runs as
+// reduce-only launches (GRU part early, conv part late) and one Adam + prepare launch that reads the summed bucket.
+// Every sum has a fixed order: results are bitwise reproducible and identical between the fused and the split form.
+#include "common.h"
+
+namespace {
+
+constexpr int FP = 16, PART = 2 * FP * FP + 2 * FP;   // GCN partial row: dW1 | dW2 | db1 | db2 (gcn.hip)
+enum { T_C1W = 0, T_C1B, T_C2W, T_C2B, T_WIH, T_WHH, T_BIH, T_BHH };
+
+template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
+__device__ __forceinline__ void emit(const FinishArgs& a, int t, int idx, int row, int col, float gval, bool write_g,
+                                     bool& bad_g, bool& bad_w) {
+  bad_g |= !(__builtin_fabsf(gval) <= 3.0e38f);                       // inf / NaN in a final gradient
+  if (write_g) a.g[t][idx] = gval;
+  if (!ADAM) return;
+  // torch.optim.Adam, single-tensor formulas in fp32, explicit roundings (the fused and the split launch agree bitwise)
+  const float mi = __fmaf_rn(a.b1, a.m[t][idx], __fmul_rn(1.f - a.b1, gval));
+  const float vi = __fmaf_rn(a.b2, a.v[t][idx], __fmul_rn(__fmul_rn(1.f - a.b2, gval), gval));
+  a.m[t][idx] = mi;
+  a.v[t][idx] = vi;
+  const float denom = __fadd_rn(__fmul_rn(__fsqrt_rn(vi), a.inv_sqrt_bc2), a.eps);
+  const float w = __fsub_rn(a.p[t][idx], __fmul_rn(a.lr_over_bc1, __fdiv_rn(mi, denom)));
+  a.p[t][idx] = w;
+  if (a.prep_kind == 0 || (t != T_WIH && t != T_BIH)) return;
+  if (t == T_BIH) { col = a.I; row = idx; }                           // b_ih rides in column I of the forward image
+  if (a.prep_kind == 1) {
+    bad_w |= out_of_fp16_range(w);
+    const _Float16 h = (_Float16)w, l = (_Float16)(w - (float)h);
+    const size_t f = (size_t)(col >> 5) * a.np_g3 * 32 + (size_t)row * 32 + (col & 31);
+    a.pf_hi[f] = h;
+    a.pf_lo[f] = l;
+    if (t == T_WIH) {
+      const size_t b = (size_t)(row >> 5) * a.np_i * 32 + (size_t)col * 32 + (row & 31);
+      a.pb_hi[b] = h;
+      a.pb_lo[b] = l;
+    }
+  } else {
+    a.wp[(size_t)row * a.Ip + col] = w;
+    if (t == T_WIH) a.wt[(size_t)col * a.Gp + row] = w;
+  }
+}
+
+// ---- split-K partials in pgemm_tn_kernel's own layout [z][tile][wave][i][j][lane][4] (pgemm.hip)
+template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
+__device__ __forceinline__ void seg_tn(const FinishArgs& a, const FinSeg& s, int tw, int tb, int blk, bool& bad_g,
+                                       bool& bad_w) {
+  const size_t slab4 = (size_t)s.ntiles * TN_WAVES * 5 * s.T * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 quads x 4 z phases per block
+  const size_t q = (size_t)blk * 64 + tx;
+  const f32x4* src = (const f32x4*)s.partial + q;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int z = ty;
+  for (; z + 12 < s.splitk; z += 16) {                               // 4 independent 16-byte loads in flight
+    s0 += src[(size_t)z * slab4];
+    s1 += src[(size_t)(z + 4) * slab4];
+    s2 += src[(size_t)(z + 8) * slab4];
+    s3 += src[(size_t)(z + 12) * slab4];
+  }
+  for (; z < s.splitk; z += 4) s0 += src[(size_t)z * slab4];
+  __shared__ f32x4 red[4][64];
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty != 0) return;
+  f32x4 v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (s.scaled) v *= a.scales[1];
+  size_t t = q;
+  const int lane = (int)(t % 64); t /= 64;
+  const int j = (int)(t % s.T); t /= s.T;
+  const int i = (int)(t % 5); t /= 5;
+  const int wave = (int)(t % TN_WAVES);
+  const int tile = (int)(t / TN_WAVES);
+  const int mb = tile / s.nNb, nb = tile % s.nNb, wm = wave & 3, wn = wave >> 2;
+  const int n = nb * 32 * s.T + 16 * (s.T * wn + j) + (lane & 15);
+  const int m0 = mb * TN_BM + 80 * wm + 16 * i + 4 * (lane >> 4);
+  if (n >= s.Nout) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int m = m0 + r;
+    if (s.msplit > 0) {                                               // two-source A operand: GEMM rows -> weight rows
+      if (m >= s.msplit) m = s.rows1 + (m - s.msplit);
+      else if (m >= s.rows1) continue;
+    }
+    if (m >= s.Mout) continue;
+    if (n < s.ncols) emit<ADAM>(a, tw, m * s.ncols + n, m, n, v[r], true, bad_g, bad_w);
+    else if (n == s.Nout - 1) emit<ADAM>(a, tb, m, m, 0, v[r], true, bad_g, bad_w);
+  }
+}
+
+// ---- split-K partials as plain [z][Mout][Nout] (gemm.hip, gemm32.hip)
+template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
+__device__ __forceinline__ void seg_plain(const FinishArgs& a, const FinSeg& s, int tw, int tb, int blk, bool& bad_g,
+                                          bool& bad_w) {
+  const size_t MN = (size_t)s.Mout * s.Nout;
+  const size_t i = (size_t)blk * 256 + threadIdx.x;
+  if (i >= MN) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+  int z = 0;
+  for (; z + 8 <= s.splitk; z += 8) {                                // 8 independent loads in flight; fixed order
+    s0 += s.partial[(size_t)z * MN + i];
+    s1 += s.partial[(size_t)(z + 1) * MN + i];
+    s2 += s.partial[(size_t)(z + 2) * MN + i];
+    s3 += s.partial[(size_t)(z + 3) * MN + i];
+    s4 += s.partial[(size_t)(z + 4) * MN + i];
+    s5 += s.partial[(size_t)(z + 5) * MN + i];
+    s6 += s.partial[(size_t)(z + 6) * MN + i];
+    s7 += s.partial[(size_t)(z + 7) * MN + i];
+  }
+  for (; z < s.splitk; ++z) s0 += s.partial[(size_t)z * MN + i];
+  float v = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+  if (s.scaled) v *= a.scales[1];
+  const int m = (int)(i / s.Nout), n = (int)(i % s.Nout);
+  if (n < s.ncols) emit<ADAM>(a, tw, m * s.ncols + n, m, n, v, true, bad_g, bad_w);
+  else if (n == s.Nout - 1) emit<ADAM>(a, tb, m, m, 0, v, true, bad_g, bad_w);
+}
+
+// ---- per-workgroup partial rows of the GCN backward, [rows][PART]: 32 columns x 8 row groups per block
+template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
+__device__ __forceinline__ void seg_conv(const FinishArgs& a, int blk, bool& bad_g, bool& bad_w) {
+  __shared__ float sm[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i = blk * 32 + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < PART) {
+    int b = ty;
+    for (; b + 24 < a.conv_rows; b += 32) {
+      s0 += a.conv_partial[(size_t)b * PART + i];
+      s1 += a.conv_partial[(size_t)(b + 8) * PART + i];
+      s2 += a.conv_partial[(size_t)(b + 16) * PART + i];
+      s3 += a.conv_partial[(size_t)(b + 24) * PART + i];
+    }
+    for (; b < a.conv_rows; b += 8) s0 += a.conv_partial[(size_t)b * PART + i];
+  }
+  sm[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty != 0 || i >= PART) return;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += sm[k][tx];
+  constexpr int F = 13;
+  if (i < FP * FP) {
+    const int r = i / FP, c = i % FP;
+    if (r < F && c < F) emit<ADAM>(a, T_C1W, r * F + c, r, c, s, true, bad_g, bad_w);
+  } else if (i < 2 * FP * FP) {
+    const int j = i - FP * FP, r = j / FP, c = j % FP;
+    if (r < F && c < F) emit<ADAM>(a, T_C2W, r * F + c, r, c, s, true, bad_g, bad_w);
+  } else if (i < 2 * FP * FP + FP) {
+    const int c = i - 2 * FP * FP;
+    if (c < F) emit<ADAM>(a, T_C1B, c, c, 0, s, true, bad_g, bad_w);
+  } else {
+    const int c = i - 2 * FP * FP - FP;
+    if (c < F) emit<ADAM>(a, T_C2B, c, c, 0, s, true, bad_g, bad_w);
+  }
+}
+
+// ---- tensors whose gradient is already final in g (after an all-reduce, or written directly by their kernel)
+template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
+__device__ __forceinline__ void seg_elem(const FinishArgs& a, int blk, bool& bad_g, bool& bad_w) {
+  int e = blk * 256 + threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (!((a.elem_mask >> t) & 1)) continue;
+    if (e < a.n[t]) {
+      const int ncols = t == T_WIH ? a.I : 1;
+      emit<ADAM>(a, t, e, e / ncols, e % ncols, a.g[t][e], false, bad_g, bad_w);
+      return;
+    }
+    e -= a.n[t];
+  }
+}
+
+template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
+__global__ void __launch_bounds__(256) finish_kernel(const FinishArgs a) {
+  int blk = blockIdx.x;
+  bool bad_g = false, bad_w = false;
+  if (blk < a.ih.nblocks) {
+    if (a.ih.kind == 2) seg_tn<ADAM>(a, a.ih, T_WIH, T_BIH, blk, bad_g, bad_w);
+    else seg_plain<ADAM>(a, a.ih, T_WIH, T_BIH, blk, bad_g, bad_w);
+  } else if ((blk -= a.ih.nblocks) < a.hh.nblocks) {
+    if (a.hh.kind == 2) seg_tn<ADAM>(a, a.hh, T_WHH, T_BHH, blk, bad_g, bad_w);
+    else seg_plain<ADAM>(a, a.hh, T_WHH, T_BHH, blk, bad_g, bad_w);
+  } else if ((blk -= a.hh.nblocks) < a.conv_blocks) {
+    seg_conv<ADAM>(a, blk, bad_g, bad_w);
+  } else {
+    seg_elem<ADAM>(a, blk - a.conv_blocks, bad_g, bad_w);
+  }
+  report_status(a.status, bad_g, WGNN_STATUS_GRAD_NONFINITE);
+  report_status(a.status, bad_w, WGNN_STATUS_WEIGHT_RANGE);
+}
+
+}  // namespace
+
+int finish_seg_blocks(const FinSeg& s) {
+  if (s.kind == 2) return (int)((size_t)s.ntiles * TN_WAVES * 5 * s.T);      // slab4 / 64
+  if (s.kind == 1) return (int)(((size_t)s.Mout * s.Nout + 255) / 256);
+  return 0;
+}
+
+// a.ih / a.hh with kind 0 and conv_partial == nullptr are skipped; elem_mask names the tensors read from g.
+int launch_finish(FinishArgs a, hipStream_t st) {
+  a.ih.nblocks = finish_seg_blocks(a.ih);
+  a.hh.nblocks = finish_seg_blocks(a.hh);
+  a.conv_blocks = a.conv_partial ? cdiv_i(PART, 32) : 0;
+  int64_t ne = 0;
+  for (int t = 0; t < 8; ++t)
+    if ((a.elem_mask >> t) & 1) ne += a.n[t];
+  a.elem_blocks = (int)((ne + 255) / 256);
+  const int grid = a.ih.nblocks + a.hh.nblocks + a.conv_blocks + a.elem_blocks;
+  if (grid < 1) return WGNN_OK;
+  double by = 0.0;
+  if (a.ih.kind) by += 4.0 * a.ih.splitk * a.ih.Mout * (double)a.ih.Nout;
+  if (a.hh.kind) by += 4.0 * a.hh.splitk * a.hh.Mout * (double)a.hh.Nout;
+  if (a.conv_partial) by += 4.0 * a.conv_rows * PART;
+  double np = 0.0;
+  for (int t = 0; t < 8; ++t) np += a.n[t];
+  by += (a.adam ? 28.0 + (a.prep_kind ? 8.0 : 0.0) : 4.0) * np;
+  if (a.adam)
+    PROF_LAUNCH("finish_kernel<1>", 12.0 * np, by, st,
+                hipLaunchKernelGGL(finish_kernel<1>, dim3(grid), dim3(256), 0, st, a));
+  else
+    PROF_LAUNCH("finish_kernel<0>", np, by, st,
+                hipLaunchKernelGGL(finish_kernel<0>, dim3(grid), dim3(256), 0, st, a));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}

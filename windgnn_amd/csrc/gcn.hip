@@ -371,41 +371,12 @@ int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float*
   return WGNN_OK;
 }
 
-size_t gcn2_bwd_partial_floats(int ntiles) { return (size_t)grid_for(ntiles) * PART; }
 size_t gcn1_bwd_partial_floats(int ntiles) { return (size_t)grid_for(ntiles) * PART; }
-
-int launch_gcn2_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                    const float* W2, const float* b2, float* g, int ldg, hipStream_t st) {
-  const double fl = (double)ntiles * 2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13);
-  const double by = (double)ntiles * S * 13 * 4.0 * 2.0;
-  PROF_LAUNCH("gcn_fwd_kernel<2>", fl, by, st,
-              hipLaunchKernelGGL(gcn_fwd_kernel<2>, dim3(grid_for(ntiles)), dim3(256), smem_bytes(S), st, ntiles, S,
-                                 13, A, X, W1, b1, W2, b2, g, ldg));
-  WGNN_CHECK_LAUNCH();
-  return WGNN_OK;
-}
 
 int launch_gcn1_fwd(int ntiles, int S, const float* A, const float* X, const float* W, const float* b, float* out,
                     hipStream_t st) {
   hipLaunchKernelGGL(gcn_fwd_kernel<1>, dim3(grid_for(ntiles)), dim3(256), smem_bytes(S), st, ntiles, S, 13, A, X, W,
                      b, (const float*)nullptr, (const float*)nullptr, out, S * 13);
-  WGNN_CHECK_LAUNCH();
-  return WGNN_OK;
-}
-
-int launch_gcn2_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                    const float* W2, const float* g, int ldg, const float* dg, float* dW1, float* db1, float* dW2,
-                    float* db2, float* partial, hipStream_t st) {
-  int grid = grid_for(ntiles);
-  // algorithmic: recompute of layer 1 + both layers' backward (64 532 flop per tile at S=34)
-  const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
-  const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
-  PROF_LAUNCH("gcn_bwd_kernel<2>", fl, by, st,
-              hipLaunchKernelGGL(gcn_bwd_kernel<2>, dim3(grid), dim3(256), smem_bytes(S), st, ntiles, S, 13, A, X, W1,
-                                 b1, W2, g, dg, (float*)nullptr, partial, ldg));
-  WGNN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gcn_partial_reduce_kernel, dim3(cdiv_i(PART, 32)), dim3(1024), 0, st, partial, grid, 13, dW1,
-                     db1, dW2, db2, (unsigned*)nullptr);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

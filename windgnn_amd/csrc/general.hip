@@ -377,8 +377,11 @@ int launch_gcn2_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float
                                  I, h1, (const _Float16*)nullptr, I, du, I, (const float*)nullptr, (float*)nullptr,
                                  scales, partial));
   WGNN_CHECK_LAUNCH();
+  if (!dW1) return WGNN_OK;              // deferred: finish.hip reduces the gcn_csr_bwd_rows() partial rows
   return launch_gcn_partial_reduce(partial, GEN_BLOCKS, dW1, db1, dW2, db2, nullptr, st);
 }
+
+int gcn_csr_bwd_rows() { return GEN_BLOCKS; }
 
 // Y, gates from GI: per step gh = Hprev W_hh^T + b_hh (GEMM, skipped at t = 0 where h = 0) and the cell.
 int launch_gru_gen_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,

@@ -1,14 +1,30 @@
-"""Data-parallel helpers.  Windows are independent (h0 = 0 per window,
+"""Data-parallel host logic.  Windows are independent (h0 = 0 per window,
 src/step6_gcn_gru_combined_model.py:23 passes no h0), so the path shards over B with no data-path
-collective; the only exchange is ONE all-reduce of the flat gradient bucket per step.
+collective; the only exchange is the sum of the flat gradient bucket, as TWO all-reduces per step
+(`BucketExchange`): the GRU gradients (99.8 % of the bytes) as soon as they are final, overlapped with the rest
+of the backward, then the conv gradients together with the loss scalar.
 
-These helpers are backend-agnostic host logic (nccl == RCCL on the GPU box, gloo in CPU tests)."""
+Backend-agnostic (nccl == RCCL over xGMI on the GPU box, gloo in the CPU tests).  `TrainStep` (trainer.py) and
+`bench.py` run exactly this class; tests/test_distributed_cpu.py runs it with the oracle standing in for the kernels.
+
+RCCL on this pool needs dmabuf IPC: `ensure_rccl_env()` exports HSA_ENABLE_IPC_MODE_LEGACY=0 and must run before the
+process initialises the GPU (bench.py calls it first thing)."""
 from __future__ import annotations
 
-from typing import Sequence, Tuple
+import os
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+HEADER = 4                  # floats in front of the gradients in the bucket (16-byte aligned); word 3 = the loss
+LOSS_SLOT = 3
+
+
+def ensure_rccl_env() -> None:
+    """The host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's (and torch's) cross-process
+    buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.  Must be set before the first HIP call."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def shard_range(n_windows: int, rank: int, world: int) -> Tuple[int, int]:
@@ -19,8 +35,9 @@ def shard_range(n_windows: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def shard_windows(X: torch.Tensor, L: torch.Tensor, rank: int, world: int):
+    """This rank's windows, as contiguous tensors (the raw entry points refuse strided views)."""
     lo, hi = shard_range(X.shape[0], rank, world)
-    return X[lo:hi], L[lo:hi]
+    return X[lo:hi].contiguous(), L[lo:hi].contiguous()
 
 
 def grad_scale_for_shard(n_local: int, n_global: int) -> float:
@@ -29,12 +46,42 @@ def grad_scale_for_shard(n_local: int, n_global: int) -> float:
     return float(n_local) / float(n_global)
 
 
-def allreduce_flat_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
-    """One sum all-reduce of the single flat gradient bucket (167 440 fp32 at S=34)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
-    return flat_grad
-
-
 def flatten(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
     return torch.cat([t.reshape(-1) for t in tensors])
+
+
+class BucketExchange:
+    """The collectives of one data-parallel step over a flat bucket `[4-float header | conv grads | GRU grads]`.
+
+    Every collective here is issued unconditionally by every rank in the same order, whatever the rank-local state
+    (a cache keyed by the local window count let one rank skip a collective another one issued).
+    The global window count either comes from the caller (`n_global`, e.g. bench.py's fixed world * B: no extra
+    collective, no host sync) or is all-reduced on EVERY call."""
+
+    def __init__(self, bucket: torch.Tensor, n_conv: int, group=None):
+        self.bucket = bucket
+        self.n_conv = n_conv
+        self.group = group
+        self.world = dist.get_world_size(group)
+
+    def shard_weight(self, n_local: int, n_global: Optional[int] = None) -> float:
+        """n_local / n_global: the dY scale of this shard and the weight of its mean loss in the global mean."""
+        if n_global is None:
+            t = torch.tensor([float(n_local)], dtype=torch.float64, device=self.bucket.device)
+            dist.all_reduce(t, group=self.group)            # every step, every rank
+            n_global = int(round(float(t.item())))
+        if n_local < 0 or n_global < n_local or n_global < 1:
+            raise RuntimeError("windgnn_amd: shard of %d windows in a global batch of %d" % (n_local, n_global))
+        return grad_scale_for_shard(n_local, n_global)
+
+    def start_gru(self):
+        """Sum the GRU gradients (final after backward parts 1|4); returns the async work handle."""
+        return dist.all_reduce(self.bucket[HEADER + self.n_conv:], group=self.group, async_op=True)
+
+    def finish(self, work, weight: float) -> None:
+        """Weight this shard's mean loss, sum the conv gradients + the loss in one small all-reduce, join `work`:
+        afterwards the bucket holds the big-batch gradient and word 3 the big-batch mean loss on every rank."""
+        if weight != 1.0:
+            self.bucket[LOSS_SLOT].mul_(weight)
+        dist.all_reduce(self.bucket[LOSS_SLOT:HEADER + self.n_conv], group=self.group)
+        work.wait()

@@ -27,6 +27,15 @@ def _require_gpu(*tensors: torch.Tensor, io_ok: bool = False) -> None:
             raise RuntimeError("windgnn_amd: expected float32 tensors, got %s" % t.dtype)
 
 
+def _require_contiguous(**named: torch.Tensor) -> None:
+    """The C ABI reads dense row-major memory from data_ptr(): a strided view (e.g. a batch slice X[::2], a transposed
+    label tensor) would be read as if it were dense.  The raw entry points refuse it; callers own the .contiguous()."""
+    for name, t in named.items():
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("windgnn_amd: %s must be contiguous (got shape %s with strides %s): call .contiguous() "
+                               "on it first" % (name, tuple(t.shape), tuple(t.stride())))
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -65,10 +74,12 @@ def _adj(A, S=None):
     return A.contiguous(), _lib.ADJ_DENSE, 0
 
 
-def _params_struct(cls, tensors: Sequence[torch.Tensor]):
+def _params_struct(cls, tensors: Sequence[torch.Tensor], prepared: torch.Tensor = None):
     s = cls()
     for (name, _), t in zip(cls._fields_, tensors):
         setattr(s, name, t.data_ptr())
+    if prepared is not None:
+        s.prepared = prepared.data_ptr()      # wgnn_params.prepared: caller-kept images of W_ih
     return s
 
 
@@ -91,7 +102,7 @@ class _Workspace:
         return buf
 
 
-_STATUS_TEXT = {1: "a graph-convolution pre-activation left fp16's range (|x| >= 65520) or was NaN",
+_STATUS_TEXT = {1: "a graph-convolution pre-activation left fp16's range (|x| > 65504) or was NaN",
                 2: "a GRU weight or bias lies outside fp16's range",
                 4: "a gradient came out inf / NaN"}
 
@@ -113,12 +124,14 @@ def check_range_status(device=None) -> None:
                                % (_lib.load().wgnn_strerror(-7).decode(), word, what))
 
 
-def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32, want_stash=True, labels=None):
+def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32, want_stash=True, labels=None,
+                        prepared=None):
     """Y[B,T,H], stash = wgnn_fwd(...).  X is [B,T,S,F].  labels [B,T,H]: wgnn_fwd_loss (the MSE statistics of
     (Y - labels) are left in the stash for gcn_gru_backward_mse_raw(..., part | 8))."""
     lib = _lib.load()
     _require_gpu(X, io_ok=True)
     _require_gpu(*params)
+    _require_contiguous(X=X, labels=labels, **{"params[%d]" % i: q for i, q in enumerate(params)})
     B, T, S, F = X.shape
     A, fmt, nnz = _adj(A, S)
     H = params[5].shape[1]
@@ -130,7 +143,7 @@ def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32
     ws = _Workspace.get(X.device, ws_bytes)
     stash = torch.empty(lib.wgnn_stash_bytes(C.byref(d)), dtype=torch.uint8, device=X.device) if want_stash else None
     Y = torch.empty(B, T, H, dtype=X.dtype, device=X.device)
-    ps = _params_struct(_lib.Params, params)
+    ps = _params_struct(_lib.Params, params, prepared)
     if labels is not None:
         _require_gpu(labels, io_ok=True)
         if labels.dtype != X.dtype:
@@ -138,7 +151,7 @@ def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32
         if labels.numel() != Y.numel() or not want_stash:
             raise RuntimeError("windgnn_amd: wgnn_fwd_loss needs a stash and labels of Y's size, got %s vs %s"
                                % (tuple(labels.shape), tuple(Y.shape)))
-        rc = lib.wgnn_fwd_loss(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(labels.contiguous()), _ptr(Y),
+        rc = lib.wgnn_fwd_loss(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(labels), _ptr(Y),
                                _ptr(stash), _ptr(ws), ws_bytes, _stream())
         _lib.check(rc, "wgnn_fwd_loss")
         return Y, stash, d
@@ -150,7 +163,10 @@ def gcn_gru_forward_raw(A, X, params: Sequence[torch.Tensor], math=_lib.MATH_F32
 def gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, grads: Sequence[torch.Tensor], part: int = 7, stream=None):
     """part bit mask (wgnn_bwd_part): 1 = BPTT recurrence, 4 = GRU weight-gradient GEMMs, 2 = dg + GCN backward."""
     lib = _lib.load()
+    _require_contiguous(X=X, Y=Y, dY=dY, **{"grads[%d]" % i: q for i, q in enumerate(grads)},
+                        **{"params[%d]" % i: q for i, q in enumerate(params)})
     A = getattr(A, "blob", A)              # CsrAdjacency -> its device buffer (d.adj_format says which it is)
+    _require_contiguous(adj_matrix=A)
     ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
     ws = _Workspace.get(X.device, ws_bytes)
     ps = _params_struct(_lib.Params, params)
@@ -161,7 +177,7 @@ def gcn_gru_backward_raw(d, A, X, params, Y, dY, stash, grads: Sequence[torch.Te
 
 
 def gcn_gru_backward_mse_raw(d, A, X, params, Y, L, stash, grads: Sequence[torch.Tensor], loss: torch.Tensor,
-                             grad_scale: float = 1.0, part: int = 7):
+                             grad_scale: float = 1.0, part: int = 7, prepared=None):
     """wgnn_bwd_mse_part: the backward of grad_scale * mean((Y - L)^2) with the loss call folded in (src/main.py:72,79);
     `loss` (0-dim device tensor) receives mean((Y - L)^2) from the call that has part bit 1."""
     lib = _lib.load()
@@ -170,14 +186,57 @@ def gcn_gru_backward_mse_raw(d, A, X, params, Y, L, stash, grads: Sequence[torch
         raise RuntimeError("windgnn_amd: labels are %s but Y is %s (one I/O type per call)" % (L.dtype, Y.dtype))
     if L.numel() != Y.numel():
         raise RuntimeError("windgnn_amd: MSE operands differ in size: %s vs %s" % (tuple(Y.shape), tuple(L.shape)))
+    _require_contiguous(X=X, Y=Y, labels=L, **{"grads[%d]" % i: q for i, q in enumerate(grads)},
+                        **{"params[%d]" % i: q for i, q in enumerate(params)})
     A = getattr(A, "blob", A)
+    _require_contiguous(adj_matrix=A)
     ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
     ws = _Workspace.get(X.device, ws_bytes)
-    ps = _params_struct(_lib.Params, params)
+    ps = _params_struct(_lib.Params, params, prepared)
     gs = _params_struct(_lib.Grads, grads)
-    rc = lib.wgnn_bwd_mse_part(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(Y), _ptr(L.contiguous()), grad_scale,
+    rc = lib.wgnn_bwd_mse_part(C.byref(d), _ptr(A), _ptr(X), C.byref(ps), _ptr(Y), _ptr(L), grad_scale,
                                _ptr(loss), _ptr(stash), C.byref(gs), _ptr(ws), ws_bytes, _stream(), part)
     _lib.check(rc, "wgnn_bwd_mse_part(%d)" % part)
+
+
+def prepared_weights(d, params, device):
+    """A fresh `prepared` buffer (wgnn_params.prepared) holding the staged images of params' W_ih / b_ih, or None when
+    this configuration has none (wgnn_prepared_bytes == 0)."""
+    lib = _lib.load()
+    nbytes = lib.wgnn_prepared_bytes(C.byref(d))
+    if nbytes == 0:
+        return None
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    refresh_prepared(d, params, buf)
+    return buf
+
+
+def refresh_prepared(d, params, prepared) -> None:
+    """wgnn_prepare_weights: rebuild the images after the caller changed W_ih / b_ih itself (load_state_dict, ...)."""
+    lib = _lib.load()
+    ws = _Workspace.get(prepared.device, _lib.STATUS_BYTES)
+    ps = _params_struct(_lib.Params, params, prepared)
+    _lib.check(lib.wgnn_prepare_weights(C.byref(d), C.byref(ps), _ptr(ws), ws.numel(), _stream()), "wgnn_prepare_weights")
+
+
+def finish_step(d, params, grads, which: int, adam=None, prepared=None, device=None) -> None:
+    """wgnn_finish: reduce the deferred partial sums of the backward parts in `which` (4: GRU, 2: conv) into `grads` and,
+    with adam = dict(exp_avg=[8 tensors], exp_avg_sq=[8 tensors], step, lr, beta1, beta2, eps), apply Adam to `params`
+    in place (and refresh `prepared`) -- one launch."""
+    lib = _lib.load()
+    ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
+    ws = _Workspace.get(device if device is not None else grads[0].device, ws_bytes)
+    ps = _params_struct(_lib.Params, params, prepared)
+    gs = _params_struct(_lib.Grads, grads)
+    ad = None
+    if adam is not None:
+        ad = _lib.Adam()
+        ad.exp_avg = _params_struct(_lib.Grads, adam["exp_avg"])
+        ad.exp_avg_sq = _params_struct(_lib.Grads, adam["exp_avg_sq"])
+        ad.step, ad.lr, ad.beta1, ad.beta2, ad.eps = adam["step"], adam["lr"], adam["beta1"], adam["beta2"], adam["eps"]
+    rc = lib.wgnn_finish(C.byref(d), C.byref(ps), C.byref(gs), which, C.byref(ad) if ad is not None else None, _ptr(ws),
+                         ws_bytes, _stream())
+    _lib.check(rc, "wgnn_finish(%d%s)" % (which, ", adam" if adam is not None else ""))
 
 
 class GCNGRUFunction(torch.autograd.Function):

@@ -6,13 +6,18 @@ windows; the 8 gradients live in ONE flat fp32 bucket (167 440 floats at S=34). 
 TWO all-reduces on RCCL's stream: the GRU gradients (99.8 % of the bytes) as soon as the weight-gradient GEMMs are
 done, overlapped with the rest of the backward (dg GEMM + GCN backward), then the 364 conv gradients together with
 the scalar loss.  dY is pre-scaled by n_local / n_global (= 1 / world_size for equal shards) so the summed bucket
-equals the gradient of the big-batch mean loss, and the returned loss is the big-batch mean loss on every rank."""
+equals the gradient of the big-batch mean loss, and the returned loss is the big-batch mean loss on every rank.
+The collectives themselves live in distributed.BucketExchange (every rank issues every collective on every step).
+
+The loss a step returns is a 0-dim VIEW of the bucket's header: read it (float(loss)) before the next step."""
 from __future__ import annotations
 
 import torch
 
 from . import _lib
-from .functional import adam_step_, check_range_status, gcn_gru_backward_mse_raw, gcn_gru_forward_raw
+from .distributed import HEADER, LOSS_SLOT, BucketExchange
+from .functional import (check_range_status, finish_step, gcn_gru_backward_mse_raw, gcn_gru_forward_raw,
+                         prepared_weights, refresh_prepared)
 from .modules import GCN_GRU
 
 
@@ -26,9 +31,9 @@ class TrainStep:
         self.flat_p = torch.cat([p.detach().reshape(-1) for p in self.params]).contiguous()
         # gradient bucket with a 4-float header (16-byte aligned bucket): header[3] = the step's loss, so that the loss
         # rides in the conv-gradient all-reduce (the conv gradients are the first 364 floats of the bucket)
-        self._gbuf = torch.zeros(self.flat_p.numel() + 4, dtype=torch.float32, device=dev)
-        self.flat_g = self._gbuf[4:]
-        self._loss = self._gbuf[3]
+        self._gbuf = torch.zeros(self.flat_p.numel() + HEADER, dtype=torch.float32, device=dev)
+        self.flat_g = self._gbuf[HEADER:]
+        self._loss = self._gbuf[LOSS_SLOT]
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.p_views, self.g_views = [], []
@@ -37,6 +42,11 @@ class TrainStep:
             p.grad = gv.view_as(p)
             self.p_views.append(p.data)
             self.g_views.append(p.grad)
+        self.m_views = [t.view_as(p) for t, p in zip(self.exp_avg.split(sizes), self.params)]
+        self.v_views = [t.view_as(p) for t, p in zip(self.exp_avg_sq.split(sizes), self.params)]
+        # the staged images of W_ih (wgnn_params.prepared): built once, then kept current by wgnn_finish's Adam; rebuilt
+        # when someone else wrote the parameters (load_state_dict, p.data.copy_, ...: torch's version counter tells)
+        self._prepared, self._prepared_version = None, None
         self.n_conv = sum(sizes[:4])
         self.lr, self.betas, self.eps = lr, betas, eps
         self.steps = 0
@@ -46,51 +56,78 @@ class TrainStep:
             self.world = torch.distributed.get_world_size(process_group)
         # an explicitly passed group runs the collective path even with one rank (the all-reduces execute)
         self.collective = self.world > 1 or process_group is not None
-        self._shard = {}                        # local window count -> (grad scale, loss weight) of this job
+        self.exchange = BucketExchange(self._gbuf, self.n_conv, process_group) if self.collective else None
         self.check_every = check_every          # f16x3 / f16: read the library's range-status word every N steps
         self.device = dev
 
-    def _scales(self, n_local: int):
-        """(n_local / n_global, equal_shards) for this local window count; one tiny all-reduce the first time a
-        count is seen (shards may differ by one window: distributed.shard_range)."""
-        if n_local not in self._shard:
-            t = torch.tensor([float(n_local), float(n_local), -float(n_local)], device=self.device, dtype=torch.float64)
-            tot = t[:1].clone()
-            torch.distributed.all_reduce(tot, group=self.group)
-            ext = t[1:].clone()
-            torch.distributed.all_reduce(ext, op=torch.distributed.ReduceOp.MAX, group=self.group)
-            self._shard[n_local] = (n_local / float(tot.item()), float(ext[0].item()) == -float(ext[1].item()))
-        return self._shard[n_local]
+    def _param_version(self):
+        """torch's in-place version counters of the parameters: load_state_dict / optimiser-free edits through the
+        nn.Parameters or the flat buffer bump them; the library's own kernels do not."""
+        return (self.flat_p._version,) + tuple(p._version for p in self.params)
+
+    def refresh(self):
+        """Call after writing parameters in a way torch does not count (p.data.copy_(...), raw pointers): the staged
+        W_ih images are rebuilt on the next step."""
+        self._prepared_version = None
+
+    def _images(self, d):
+        if self._prepared is None:
+            self._prepared = prepared_weights(d, self.p_views, self.device)
+        else:
+            refresh_prepared(d, self.p_views, self._prepared)
+        self._prepared_version = self._param_version()
+
+    def _adam(self):
+        return dict(exp_avg=self.m_views, exp_avg_sq=self.v_views, step=self.steps, lr=self.lr, beta1=self.betas[0],
+                    beta2=self.betas[1], eps=self.eps)
 
     def forward_backward(self, A, X, L):
-        """src/main.py:66,72,79: returns (loss, Y); gradients land in the flat bucket."""
-        Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True, labels=L)
+        """src/main.py:66,72,79: returns (loss, Y); gradients land in the flat bucket (no optimiser step)."""
+        X, L = X.contiguous(), L.contiguous()
+        Y, stash, d = self._forward(A, X, L)
         loss = self._loss
-        gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0, part=7 | 8)
+        gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0, part=7 | 8,
+                                 prepared=self._prepared)
         return loss, Y
 
-    def step(self, A, X, L):
+    def _forward(self, A, X, L):
+        # the first call sizes and builds the images from the dims of this batch (they depend on S, H, math only)
+        if self._prepared_version != self._param_version():
+            from .functional import _IO_OF, _adj
+            B, T, S, F = X.shape
+            _, fmt, nnz = _adj(A, S)
+            self._images(_lib.Dims(B, T, S, F, self.p_views[5].shape[1], self.model.math, fmt, nnz, _IO_OF[X.dtype]))
+        return gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True, labels=L, prepared=self._prepared)
+
+    def step(self, A, X, L, n_global=None):
+        """One optimiser step on this rank's windows (src/main.py:66-80).  `n_global`: windows of ALL ranks in this step,
+        when the caller knows it (a fixed global batch); None = the exchange all-reduces the count on every step (a host
+        sync).  Launch-sized tail: ONE wgnn_finish (reduce the deferred partial sums + Adam + next step's W_ih images);
+        with a process group three of them around the two all-reduces."""
+        X, L = X.contiguous(), L.contiguous()   # a strided batch slice is copied here, never read as if dense
+        DEFER = _lib.BWD_DEFER
+        self.steps += 1
+        loss = self._loss
         if self.collective:
             # Overlap: the GRU gradients (99.8 % of the bucket) are final after parts 1|4 of the backward, so
             # their all-reduce runs on RCCL's stream while part 2 (dg GEMM + GCN backward, ~30 % of the
             # step) still computes; the 364 conv gradients and the loss follow in a second, tiny all-reduce.
-            gs, equal = self._scales(X.shape[0])
-            Y, stash, d = gcn_gru_forward_raw(A, X, self.p_views, self.model.math, want_stash=True, labels=L)
-            loss = self._loss
-            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=1 | 4 | 8)
-            if not equal:
-                loss.mul_(gs * self.world)      # weight of this shard's mean in the global mean, times world
-            work = torch.distributed.all_reduce(self.flat_g[self.n_conv:], group=self.group, async_op=True)
-            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=2)
-            torch.distributed.all_reduce(self._gbuf[3:4 + self.n_conv], group=self.group)
-            work.wait()
-            loss = loss / self.world            # sum of the shard means (weighted if unequal) -> big-batch mean
+            gs = self.exchange.shard_weight(X.shape[0], n_global)
+            Y, stash, d = self._forward(A, X, L)
+            pre = self._prepared
+            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=1 | 4 | 8 | DEFER,
+                                     prepared=pre)
+            finish_step(d, self.p_views, self.g_views, 4, device=self.device)
+            work = self.exchange.start_gru()
+            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=2 | DEFER, prepared=pre)
+            finish_step(d, self.p_views, self.g_views, 2, device=self.device)
+            self.exchange.finish(work, gs)      # loss: sum of the weighted shard means = the big-batch mean
+            finish_step(d, self.p_views, self.g_views, 0, self._adam(), pre, self.device)      # src/main.py:80
         else:
-            loss, Y = self.forward_backward(A, X, L)
-            loss = loss.clone()
-        self.steps += 1
-        adam_step_(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.steps, self.lr,
-                   self.betas[0], self.betas[1], self.eps)                   # src/main.py:80
+            Y, stash, d = self._forward(A, X, L)
+            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0, part=7 | 8 | DEFER,
+                                     prepared=self._prepared)
+            finish_step(d, self.p_views, self.g_views, 6, self._adam(), self._prepared, self.device)   # :79 tail + :80
         if self.check_every and self.model.math != _lib.MATH_F32 and self.steps % self.check_every == 0:
             self.check()
         return loss, Y
