@@ -47,11 +47,13 @@ extern "C" {
  * handling an error.  The fp16-plane math modes (WGNN_MATH_F16X3 / WGNN_MATH_F16) hold activations and weights as
  * fp16 (hi [+ lo]) and cannot represent magnitudes > 65504 (anything beyond is flagged); the reference's fp32 path has no such limit, so
  * instead of producing inf/NaN (or, behind a ReLU, silently 0) the kernels report it here.  WGNN_MATH_F32 never
- * sets a bit. */
+ * sets a range bit. */
 #define WGNN_STATUS_BYTES 256
 #define WGNN_STATUS_ACT_RANGE 1u    /* a GCN pre-activation left fp16's range (or was NaN) in the forward */
 #define WGNN_STATUS_WEIGHT_RANGE 2u /* a GRU weight / bias left fp16's range */
 #define WGNN_STATUS_GRAD_NONFINITE 4u /* a final gradient is inf / NaN */
+#define WGNN_STATUS_NO_LOSS_STATS 8u  /* wgnn_bwd_mse_part(part | 8) on a stash whose last forward was not wgnn_fwd_loss:
+                                         loss[0] is NaN and the gradients are not to be used (any math mode) */
 
 typedef enum wgnn_status {
   WGNN_OK = 0,

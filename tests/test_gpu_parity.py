@@ -1135,3 +1135,37 @@ def test_finish_kernel_equals_the_separate_reduce_adam_and_prepare_passes(S, T, 
         assert torch.equal(a, b)
     assert (split[4] is None and fused[4] is None) or torch.equal(split[4], fused[4])
     assert split[5] == fused[5]
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+def test_backward_told_the_loss_statistics_are_in_the_stash_when_they_are_not_is_loud(math):
+    """bit 8 of `part` ("the forward was wgnn_fwd_loss on these labels") was trusted blindly.  wgnn_fwd_loss now
+    tags its statistics, a plain wgnn_fwd on the same stash clears the tag, and the BPTT kernel that would consume them
+    writes loss = NaN and raises the status bit instead of using whatever lies there."""
+    from windgnn_amd import _lib
+    from windgnn_amd.functional import check_range_status, gcn_gru_backward_mse_raw, gcn_gru_forward_raw
+    dev = _dev()
+    fx = load_fixture("f3b_s34_t24_b4_rand")
+    A = torch.from_numpy(fx["A"]).to(dev)
+    X = torch.from_numpy(fx["X"]).repeat(300, 1, 1, 1).to(dev)     # B = 1200: past the one-window-per-workgroup kernels
+    L = torch.from_numpy(fx["L"]).repeat(300, 1, 1).to(dev)
+    model = _model_from(fx["params"], 34, 102, math)
+    ps = list(model.hot_path_parameters())
+    gs = [torch.empty_like(q) for q in ps]
+    loss = torch.zeros((), device=dev)
+    Y, stash, d = gcn_gru_forward_raw(A, X, ps, model.math, labels=L)          # wgnn_fwd_loss: tagged
+    gcn_gru_backward_mse_raw(d, A, X, ps, Y, L, stash, gs, loss, 1.0, part=7 | 8)
+    check_range_status(dev)
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-5
+    good = [q.clone() for q in gs]
+    Y2, stash2, d2 = gcn_gru_forward_raw(A, X, ps, model.math)                 # plain wgnn_fwd: tag cleared
+    gcn_gru_backward_mse_raw(d2, A, X, ps, Y2, L, stash2, gs, loss, 1.0, part=7 | 8)
+    assert torch.isnan(loss)
+    with pytest.raises(RuntimeError, match="wgnn_fwd_loss"):
+        check_range_status(dev)
+    # and without bit 8 the same stash gives the right answer (the statistics pass / the dY pass runs)
+    gcn_gru_backward_mse_raw(d2, A, X, ps, Y2, L, stash2, gs, loss, 1.0, part=7)
+    check_range_status(dev)
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-5
+    for a, b in zip(gs, good):
+        assert rel_to_max(a.cpu(), b.cpu()) <= 1e-5

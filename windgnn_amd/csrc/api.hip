@@ -26,9 +26,10 @@ struct Layout {
   // shapes beyond the fast kernels (CSR adjacency, wide hidden state) use general.hip in exact fp32
   bool x3, gen_gcn, gen_gru, g32, g32tn;
   int hq;
-  size_t ws_hprev;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
-  bool dghn;                                     // fast f16x3 recurrence: only the n third of dGH is stored (dGHn planes)
+  bool small, rec32;                             // exact fp32: one-window-per-workgroup recurrences / the register-resident MFMA ones
+  size_t st_hprev;                               // exact fp32, large B*T: [Hprev | 1 | 0..] rows written by the forward recurrence
+  bool dghn;                                     // only the n third of dGH is stored (dGHn): fast f16x3 recurrence; rec32 at large B*T
   int hn, msplit, m_hh;                          // its row width, its first GEMM row, GEMM rows of the dW_hh product
   size_t st_h1;                                  // general GCN: layer-1 activations
   size_t st_stats;                               // wgnn_fwd_loss: MSE partial pairs (sum | max) of the forward recurrence
@@ -62,6 +63,8 @@ Layout make_layout(const wgnn_dims* d) {
   // exact fp32 at large B*T: the big-tile GEMMs of gemm32.hip on zero-padded copies of W_ih / W_ih^T
   L.g32 = !x3 && !L.gen_gcn && !L.gen_gru && gemm32_nt_supported(L.BT, (int)L.Ip, (int)L.Gp);
   L.g32tn = L.g32 && gemm32_tn_supported(L.BT);          // the split-K dW products (same threshold today)
+  L.small = !x3 && !L.gen_gru && gru_small_supported(d->B, d->H);
+  L.rec32 = !x3 && !L.gen_gru && !L.small;
   // the images of W_ih the GEMMs stage: sized from S and H alone (the exact-fp32 ones are USED from B*T >= 4096 only),
   // so that a caller-kept copy (wgnn_params.prepared) serves every batch size
   const bool g32_shape = !x3 && !L.gen_gcn && !L.gen_gru && gemm32_nt_supported(1u << 30, (int)L.Ip, (int)L.Gp);
@@ -86,23 +89,27 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_xtail_f = o; o += al((L.I & 1) && !L.gen_gcn ? L.I + 1 : 0);        // private copy of X's last tile (odd S*13: see xtail_copy)
   // wgnn_fwd_last where the recurrence writes all of Y: wgnn_fwd_last has no stash, so g lives in ws_g and is dead once GI
   // is formed -- Y aliases it whenever it fits (H <= Ip: always when H = 3S), and only otherwise gets a region of its own
-  if ((x3 && !L.gen_gru) || L.H <= L.Ip) { L.ws_Ylast = L.ws_g; }
+  if ((x3 && !L.gen_gru) || L.rec32 || L.H <= L.Ip) { L.ws_Ylast = L.ws_g; }
   else { L.ws_Ylast = o; o += al(L.BT * L.H); }
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
   {  // r, z, n, gh_n of every step: [B*T][4H] fp32, or the register-resident recurrences' own record layout
-    const size_t plain = L.BT * 4 * L.H, rec = (x3 && !L.gen_gru) ? grux_gates_floats(d->B, d->T, d->H, d->io) : 0;
+    const size_t plain = L.BT * 4 * L.H, rec = (x3 && !L.gen_gru) ? grux_gates_floats(d->B, d->T, d->H, d->io)
+                                                                   : (L.rec32 ? gru_gates_floats(d->B, d->T, d->H) : 0);
     L.st_gates = o; o += al(plain > rec ? plain : rec);
   }
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
   L.st_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
-  L.st_stats = o; o += al(2 * (size_t)grux_blocks(d->B));
+  L.st_stats = o; o += al(2 * (size_t)grux_blocks(d->B) + 4);      // partial pairs (sum | max) + the tag word (gru_blocks == grux_blocks)
+  L.hq = (int)rup(L.H + 1, 16);
+  L.st_hprev = o; o += al(L.g32tn ? L.BT * (size_t)L.hq : 0);     // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
   L.stash_floats = o;
-  L.dghn = x3 && !L.gen_gru;
-  L.hn = grux_hn(d->H);
-  L.msplit = grux_msplit(d->H);
-  L.m_hh = L.dghn ? L.msplit + L.hn : (int)L.G3;
+  L.dghn = (x3 && !L.gen_gru) || (L.rec32 && L.g32tn);
+  L.hn = x3 ? grux_hn(d->H) : gru_hn(d->H);
+  L.msplit = x3 ? grux_msplit(d->H) : gru_msplit(d->H);
+  // GEMM rows of the dW_hh product: [dGI_r | dGI_z | pad to msplit | dGHn]
+  L.m_hh = L.dghn ? (x3 ? L.msplit + L.hn : L.msplit + (int)L.H) : (int)L.G3;
   if (x3) {
     L.sk_ih = pick_splitk(L.BT, pgemm_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64);   // one workgroup per CU
     L.sk_hh = pick_splitk(L.BT, pgemm_tn_tiles(L.m_hh, (int)L.H + 1), 256, 64);
@@ -110,11 +117,11 @@ Layout make_layout(const wgnn_dims* d) {
     // K chunks of at least 128 rows (B*T = 6144 at BASELINE configs[1]: with 256-row chunks the dW_hh product had 72 workgroups)
     L.sk_ih = L.g32tn ? pick_splitk(L.BT, gemm32_tn_tiles((int)L.G3, (int)L.I + 1), 256, 64)   // one workgroup per CU
                     : pick_splitk(L.BT, gemm_f32_tiles((int)L.G3, (int)L.I + 1), 1024, 128);
-    L.sk_hh = L.g32tn ? pick_splitk(L.BT, gemm32_tn_tiles((int)L.G3, (int)L.H + 1), 256, 64)
+    L.sk_hh = L.g32tn ? pick_splitk(L.BT, gemm32_tn_tiles(L.m_hh, (int)L.H + 1), 256, 64)
                     : pick_splitk(L.BT, gemm_f32_tiles((int)L.G3, (int)L.H + 1), 1024, 128);
   }
   size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
-  size_t part_hh = (size_t)L.sk_hh * L.G3 * (L.H + 1);
+  size_t part_hh = (size_t)L.sk_hh * (size_t)L.m_hh * (L.H + 1);
   if (x3) {
     part_ih = pgemm_tn_partial_floats((int)L.G3, (int)L.I + 1, L.sk_ih);
     part_hh = pgemm_tn_partial_floats(L.m_hh, (int)L.H + 1, L.sk_hh);
@@ -130,8 +137,6 @@ Layout make_layout(const wgnn_dims* d) {
     if (L.gen_gcn) a = gcn_csr_bwd_partial_floats();
     L.ws_gcnpart = o; o += al(a > b ? a : b);
   }
-  L.hq = (int)rup(L.H + 1, 16);
-  L.ws_hprev = o; o += al(L.g32tn ? L.BT * (size_t)L.hq : 0);    // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
   L.ws_du = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
   L.ws_dhz = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
   L.ws_dhw = o; o += al(L.gen_gru ? (size_t)d->B * L.H : 0);
@@ -144,6 +149,46 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_xtail_b = o; o += al((L.I & 1) && !L.gen_gcn ? L.I + 1 : 0);
   L.bwd_floats = o;
   return L;
+}
+
+// The reduction half of a finish launch: which & 4 -> the split-K partials of the two GRU weight-gradient products,
+// which & 2 -> the per-workgroup partial rows of the GCN backward; gradients go to `g`.
+void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float* ws, int which, FinishArgs& a) {
+  a.scales = ws + L.ws_scales;
+  a.status = (unsigned*)ws;
+  float* gs[8] = {g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, g->w_ih, g->w_hh, g->b_ih, g->b_hh};
+  const int F = d->F;
+  const int64_t n[8] = {(int64_t)F * F, F, (int64_t)F * F, F, (int64_t)L.G3 * (int64_t)L.I, (int64_t)L.G3 * (int64_t)L.H,
+                        (int64_t)L.G3, (int64_t)L.G3};
+  for (int t = 0; t < 8; ++t) {
+    a.g[t] = gs[t];
+    a.n[t] = (int)n[t];
+  }
+  a.I = (int)L.I;
+  if (which & 4) {
+    FinSeg& ih = a.ih;
+    ih.partial = ws + L.ws_part_ih;
+    ih.splitk = L.sk_ih;
+    ih.kind = L.x3 ? 2 : 1;
+    ih.Mout = ih.Mgemm = (int)L.G3; ih.Nout = (int)L.I + 1; ih.ncols = (int)L.I;
+    ih.scaled = L.x3;
+    FinSeg& hh = a.hh;
+    hh = ih;
+    hh.partial = ws + L.ws_part_hh;
+    hh.splitk = L.sk_hh;
+    hh.Nout = (int)L.H + 1; hh.ncols = (int)L.H;
+    hh.Mgemm = L.m_hh;
+    if (L.dghn) { hh.msplit = L.msplit; hh.rows1 = 2 * d->H; }     // GEMM rows [dGI_r | dGI_z | pad | dGHn]
+    if (L.x3) {
+      pgemm_tn_geom((int)L.G3, ih.Nout, &ih.T, &ih.nNb, &ih.ntiles);
+      pgemm_tn_geom(L.m_hh, hh.Nout, &hh.T, &hh.nNb, &hh.ntiles);
+    }
+  }
+  if (which & 2) {
+    a.conv_partial = ws + L.ws_gcnpart;
+    a.conv_rows = L.gen_gcn ? gcn_csr_bwd_rows()
+                            : (L.x3 ? gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3) : gcn32_bwd_grid((int)L.BT));
+  }
 }
 
 int check_dims(const wgnn_dims* d) {
@@ -189,7 +234,8 @@ const char* wgnn_strerror(int status) {
     case WGNN_ERR_HIP: return "HIP runtime error (kernel launch failed)";
     case WGNN_ERR_RANGE:
       return "a value left fp16's range in an fp16-plane math mode (status block bits: 1 activation, 2 weight, 4 "
-             "non-finite gradient): normalise the inputs or use WGNN_MATH_F32";
+             "non-finite gradient): normalise the inputs or use WGNN_MATH_F32; or (bit 8) the backward was told the "
+             "forward's loss statistics are in the stash but the last forward on it was not wgnn_fwd_loss";
     default: return "unknown status";
   }
 }
@@ -222,7 +268,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   if (workspace_bytes < sizeof(float) * L.fwd_floats) return WGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
-  if (last && !(L.x3 && !L.gen_gru)) Y = ws + L.ws_Ylast;   // these recurrences write every row: then read the last one out
+  if (last && !(L.x3 && !L.gen_gru) && !L.rec32) Y = ws + L.ws_Ylast;   // these recurrences write every row: then read the last one out
   unsigned* status = (unsigned*)workspace;           // word 0 of the status block (include/windgnn.h)
   float* sf = (float*)stash;
   float* GI = ws + L.ws_GI;
@@ -266,6 +312,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
       return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, last, nullptr, nullptr, full, status,
                              nullptr, nullptr, 0, 1, y_mul, y_add, st);
     // labels (wgnn_fwd_loss): the recurrence also leaves the MSE partial sums / maxima of (Y - labels) in the stash
+    // (a stash without labels gets its tag word cleared: bit 8 of a later backward cannot trust stale statistics)
     return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
                            full, status, sf ? labels : nullptr, sf ? sf + L.st_stats : nullptr, d->io, 0, 1.f, 0.f, st);
   }
@@ -294,12 +341,17 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
     rc = launch_gemm_f32(ga, st);
   }
   if (rc != WGNN_OK) return rc;
+  float* hprev = (sf && L.g32tn) ? sf + L.st_hprev : nullptr;      // [Hprev | 1 | 0..] rows for the backward's dW_hh GEMM
   if (L.gen_gru)
     rc = launch_gru_gen_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, ws + L.ws_gh, st);
-  else if (gru_small_supported(d->B, d->H))   // few windows: one per workgroup instead of sixteen
-    rc = launch_gru_small_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, st);
-  else
-    rc = launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, st);
+  else if (L.small)   // few windows: one per workgroup instead of sixteen
+    rc = launch_gru_small_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, hprev, L.hq, st);
+  else if (last)      // the register-resident recurrence writes the read-out itself
+    return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, last, nullptr, nullptr, nullptr, nullptr, 0, 1,
+                          y_mul, y_add, st);
+  else                // labels (wgnn_fwd_loss): the recurrence also leaves the MSE partial sums of (Y - labels) in the stash
+    return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates,
+                          sf ? (const float*)labels : nullptr, sf ? sf + L.st_stats : nullptr, hprev, L.hq, 0, 1.f, 0.f, st);
   if (rc != WGNN_OK || !last) return rc;
   return wgnn_predict_last((const float*)Y, d->B, d->T, d->H, wind_min, wind_max, last, stream);
 }
@@ -362,40 +414,7 @@ int wgnn_finish(const wgnn_dims* d, const wgnn_params* p, const wgnn_grads* g, i
   if (workspace_bytes < sizeof(float) * L.bwd_floats) return WGNN_ERR_WORKSPACE;
   float* ws = (float*)workspace;
   FinishArgs a = {};
-  a.scales = ws + L.ws_scales;
-  a.status = (unsigned*)workspace;
-  float* gs[8] = {g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias, g->w_ih, g->w_hh, g->b_ih, g->b_hh};
-  const int F = d->F;
-  const int64_t n[8] = {(int64_t)F * F, F, (int64_t)F * F, F, (int64_t)L.G3 * (int64_t)L.I, (int64_t)L.G3 * (int64_t)L.H,
-                        (int64_t)L.G3, (int64_t)L.G3};
-  for (int t = 0; t < 8; ++t) {
-    a.g[t] = gs[t];
-    a.n[t] = (int)n[t];
-  }
-  a.I = (int)L.I;
-  if (which & 4) {   // the two GRU weight-gradient products of wgnn_bwd*_part(4 | WGNN_BWD_DEFER)
-    FinSeg& ih = a.ih;
-    ih.partial = ws + L.ws_part_ih;
-    ih.splitk = L.sk_ih;
-    ih.kind = L.x3 ? 2 : 1;
-    ih.Mout = (int)L.G3; ih.Nout = (int)L.I + 1; ih.ncols = (int)L.I;
-    ih.scaled = L.x3;
-    FinSeg& hh = a.hh;
-    hh = ih;
-    hh.partial = ws + L.ws_part_hh;
-    hh.splitk = L.sk_hh;
-    hh.Nout = (int)L.H + 1; hh.ncols = (int)L.H;
-    if (L.x3) {
-      pgemm_tn_geom((int)L.G3, ih.Nout, &ih.T, &ih.nNb, &ih.ntiles);
-      pgemm_tn_geom(L.m_hh, hh.Nout, &hh.T, &hh.nNb, &hh.ntiles);
-      if (L.dghn) { hh.msplit = L.msplit; hh.rows1 = 2 * d->H; }
-    }
-  }
-  if (which & 2) {   // the GCN backward's per-workgroup partial rows of wgnn_bwd*_part(2 | WGNN_BWD_DEFER)
-    a.conv_partial = ws + L.ws_gcnpart;
-    a.conv_rows = L.gen_gcn ? gcn_csr_bwd_rows()
-                            : (L.x3 ? gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3) : gcn32_bwd_grid((int)L.BT));
-  }
+  fill_reduce(L, d, g, ws, which, a);
   if (adam) {
     if (!p->conv1_weight || !p->conv1_bias || !p->conv2_weight || !p->conv2_bias || !p->w_ih || !p->w_hh || !p->b_ih ||
         !p->b_hh)
@@ -482,7 +501,14 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
   float* scales = ws + L.ws_scales;          // [0] = 2^k, [1] = 2^-k (f16x3 range scaling), [2] = dY coefficient; partials from 64
   const bool x3 = L.x3;
   const bool full = d->math == WGNN_MATH_F16X3;
-  const bool fused_loss = labels && x3 && !L.gen_gru;      // the recurrence kernel forms dY from the labels itself
+  auto reduce_now = [&](int parts) {                 // without WGNN_BWD_DEFER: the reduce-only form of the finish launch
+    FinishArgs fa = {};
+    fill_reduce(L, d, g, ws, parts, fa);
+    return launch_finish(fa, st);
+  };
+  // the recurrence kernel forms dY from the labels itself: the fast f16x3 recurrence always (its statistics pass is
+  // cheap), the exact-fp32 register-resident one when the forward left the loss statistics in the stash
+  const bool fused_loss = labels && ((x3 && !L.gen_gru) || (L.rec32 && stats_ready));
   // 16-bit labels / Y: the statistics must come from wgnn_fwd_loss (the stand-alone pass reads fp32 only)
   if (d->io != WGNN_IO_F32 && labels && do_rec && !(fused_loss && stats_ready)) return WGNN_ERR_UNSUPPORTED;
   if (labels && !fused_loss && do_rec) {                   // other kernels: materialise dY in the workspace
@@ -500,9 +526,8 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     const _Float16* yph = (const _Float16*)(sf + L.st_yp);
     const size_t PG = L.BT * L.Gp;
     if (do_rec) {
-      if (fused_loss && stats_ready)   // the forward recurrence already reduced (Y - labels): only the 1-block finalize
-        rc = launch_mse_stats_finalize(sf + L.st_stats, grux_blocks(d->B), (int64_t)L.BT * L.H, grad_scale, loss, scales,
-                                       st);
+      if (fused_loss && stats_ready)   // the forward recurrence already reduced (Y - labels): the BPTT kernel finalises
+        rc = WGNN_OK;
       else if (fused_loss)   // loss, the range scale and the dY coefficient in one pass over Y and the labels
         rc = launch_mse_stats(Y, labels, (int64_t)L.BT * L.H, grad_scale, loss, scales, scales + 64, st);
       else
@@ -516,7 +541,9 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
                                    (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, ws + L.ws_kp_b, ws + L.ws_dc, full, st);
       } else {
         rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Yv, fused_loss ? nullptr : dY, fused_loss ? labelsv : nullptr,
-                             d->io, gates, scales, dGIh, dGHh, (int)L.Gp, full, st);
+                             d->io, gates, scales, dGIh, dGHh, (int)L.Gp, full,
+                             fused_loss && stats_ready ? sf + L.st_stats : nullptr, (int64_t)L.BT * L.H, grad_scale, loss,
+                             scales, status, st);
       }
       if (rc != WGNN_OK) return rc;
     }
@@ -527,26 +554,16 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       if (L.dghn) {
         rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
                              L.sk_hh, part_hh, L.m_hh, (int)L.H + 1, full, dGHh, dGHh + L.BT * (size_t)L.hn, L.hn, L.msplit, st);
-        if (rc != WGNN_OK) return rc;
-        if (!defer)
-          rc = launch_pgemm_tn_reduce(part_hh, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
-                                      status, L.msplit, 2 * d->H, L.m_hh, st);
       } else {
         rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
                              L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, full, nullptr, nullptr, 0, 0, st);
-        if (rc != WGNN_OK) return rc;
-        if (!defer)
-          rc = launch_pgemm_tn_reduce(part_hh, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, scales,
-                                      status, 0, 0, (int)L.G3, st);
       }
       if (rc != WGNN_OK) return rc;
       // dW_ih | db_ih = dGI^T [g | 1]
       rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part_ih,
                            (int)L.G3, (int)L.I + 1, full, nullptr, nullptr, 0, 0, st);
       if (rc != WGNN_OK) return rc;
-      if (!defer)
-        rc = launch_pgemm_tn_reduce(part_ih, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, scales,
-                                    status, 0, 0, (int)L.G3, st);
+      if (!defer) rc = reduce_now(4);
       if (rc != WGNN_OK) return rc;
     }   // the four GRU gradients are final here: a data-parallel caller can start reducing them now
     if (!do_gcn) return WGNN_OK;
@@ -558,34 +575,40 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.I,
                          (int)L.I, nullptr, full, nullptr, st);
     if (rc != WGNN_OK) return rc;
-    if (L.gen_gcn)
-      return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
-                                 L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, defer ? nullptr : g->conv1_weight,
-                                 g->conv1_bias, g->conv2_weight, g->conv2_bias, st);
+    if (L.gen_gcn) {
+      rc = launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
+                                 L.I, scales, ws + L.ws_du, ws + L.ws_gcnpart, nullptr, nullptr, nullptr, nullptr, st);
+      if (rc != WGNN_OK || defer) return rc;
+      return reduce_now(2);
+    }
     rc = launch_gcnx2_bwd((int)L.BT, d->S, A, Xv, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
                           scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, ws + L.ws_xtail_b, st);
     if (rc != WGNN_OK || defer) return rc;
-    return launch_gcn_partial_reduce(ws + L.ws_gcnpart, gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3), g->conv1_weight, g->conv1_bias,
-                                     g->conv2_weight, g->conv2_bias, status, st);
+    return reduce_now(2);
   }
 
   if (do_rec) {
     if (L.gen_gru)
       rc = launch_gru_gen_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, ws + L.ws_dhz,
                               ws + L.ws_dhw, st);
-    else if (gru_small_supported(d->B, d->H))
+    else if (L.small)
       rc = launch_gru_small_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
-    else
-      rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
+    else   // register-resident recurrence: dGHn alone when the dW_hh GEMM has the two-source A operand; fused loss
+      rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, fused_loss ? nullptr : dY, fused_loss ? labels : nullptr, gates,
+                          dGI, (int)L.Gp, L.dghn ? dGH : nullptr, L.dghn ? nullptr : dGH,
+                          fused_loss ? sf + L.st_stats : nullptr, (int64_t)L.BT * L.H, grad_scale, loss, status, st);
     if (rc != WGNN_OK) return rc;
   }
   if (do_wg) {
     // dW_hh = dGH^T Hprev, db_hh = dGH^T 1   (Hprev row (b,t) = Y row (b,t-1), zero at t = 0)
-    if (L.g32tn) {
-      float* hp = ws + L.ws_hprev;
-      rc = launch_hprev_pad(Y, d->B, d->T, d->H, hp, L.hq, st);
-      if (rc != WGNN_OK) return rc;
-      rc = launch_gemm32_tn(dGH, (int)L.Gp, hp, L.hq, (int)L.BT, L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, st);
+    if (L.g32tn) {     // [Hprev | 1 | 0..] rows were written by the forward recurrence (stash)
+      const float* hp = sf + L.st_hprev;
+      if (L.dghn)      // dGH = [dGI_r | dGI_z | dGHn]: GEMM rows < msplit from dGI, the rest from dGHn
+        rc = launch_gemm32_tn(dGI, (int)L.Gp, hp, L.hq, (int)L.BT, L.sk_hh, part_hh, L.m_hh, (int)L.H + 1, dGH, L.hn,
+                              L.msplit, st);
+      else
+        rc = launch_gemm32_tn(dGH, (int)L.Gp, hp, L.hq, (int)L.BT, L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, nullptr, 0, 0,
+                              st);
     } else {
       GemmArgs a = {};
       a.A = dGH; a.lda = (int)L.Gp; a.a_kcontig = 0;
@@ -595,12 +618,10 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       rc = launch_gemm_f32(a, st);
     }
     if (rc != WGNN_OK) return rc;
-    if (!defer)
-      rc = launch_splitk_reduce(part_hh, L.sk_hh, (int)L.G3, (int)L.H + 1, g->w_hh, (int)L.H, (int)L.H, g->b_hh, nullptr, st);
-    if (rc != WGNN_OK) return rc;
     // dW_ih = dGI^T g, db_ih = dGI^T 1
     if (L.g32tn) {     // g carries its ones column (gcn32_fwd)
-      rc = launch_gemm32_tn(dGI, (int)L.Gp, gact, (int)L.Ip, (int)L.BT, L.sk_ih, part_ih, (int)L.G3, (int)L.I + 1, st);
+      rc = launch_gemm32_tn(dGI, (int)L.Gp, gact, (int)L.Ip, (int)L.BT, L.sk_ih, part_ih, (int)L.G3, (int)L.I + 1, nullptr, 0,
+                            0, st);
     } else {
       GemmArgs b = {};
       b.A = dGI; b.lda = (int)L.Gp; b.a_kcontig = 0;
@@ -610,8 +631,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       rc = launch_gemm_f32(b, st);
     }
     if (rc != WGNN_OK) return rc;
-    if (!defer)
-      rc = launch_splitk_reduce(part_ih, L.sk_ih, (int)L.G3, (int)L.I + 1, g->w_ih, (int)L.I, (int)L.I, g->b_ih, nullptr, st);
+    if (!defer) rc = reduce_now(4);
     if (rc != WGNN_OK) return rc;
   }
   if (!do_gcn) return WGNN_OK;
@@ -634,12 +654,13 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     if (rc != WGNN_OK) return rc;
   }
   if (L.gen_gcn)
-    return launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, gact, nullptr, L.Ip, dg,
-                               L.I, nullptr, ws + L.ws_du, ws + L.ws_gcnpart, defer ? nullptr : g->conv1_weight,
-                               g->conv1_bias, g->conv2_weight, g->conv2_bias, st);
-  return launch_gcn32_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
-                         defer ? nullptr : g->conv1_weight, g->conv1_bias, g->conv2_weight, g->conv2_bias,
-                         ws + L.ws_gcnpart, ws + L.ws_xtail_b, st);
+    rc = launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, gact, nullptr, L.Ip, dg,
+                             L.I, nullptr, ws + L.ws_du, ws + L.ws_gcnpart, nullptr, nullptr, nullptr, nullptr, st);
+  else
+    rc = launch_gcn32_bwd((int)L.BT, d->S, A, X, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg,
+                          nullptr, nullptr, nullptr, nullptr, ws + L.ws_gcnpart, ws + L.ws_xtail_b, st);
+  if (rc != WGNN_OK || defer) return rc;
+  return reduce_now(2);
 }
 }  // namespace
 

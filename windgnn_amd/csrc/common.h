@@ -104,13 +104,9 @@ int launch_pad_weight(const float* W, int R, int C, int transpose, const float* 
                       hipStream_t st);
 int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, hipStream_t st);
 int gemm32_tn_tiles(int Mo, int No);
-int launch_hprev_pad(const float* Y, int B, int T, int H, float* out, int ld, hipStream_t st);
+// A2 != null: GEMM columns m >= msplit of the A operand come from A2 (column m - msplit, row stride lda2)
 int launch_gemm32_tn(const float* A, int lda, const float* B, int ldb, int K, int splitk, float* P, int Mo, int No,
-                     hipStream_t st);
-// C[m*ldc+n] = sum_z partial[z][m][n] for n < ncols_main; bias_out[m] = sum_z partial[z][m][N-1] if bias_out
-int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* C, int ldc,
-                         int ncols_main, float* bias_out, const float* scales /*nullable: *= scales[1]*/,
-                         hipStream_t st);
+                     const float* A2, int lda2, int msplit, hipStream_t st);
 
 int launch_mse_stats(const float* Y, const float* L, int64_t n, float grad_scale, float* loss, float* scales,
                      float* part /*>= 2048 floats*/, hipStream_t st);
@@ -123,17 +119,18 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
                     float* gates, void* y_planes, bool x3, unsigned* status, const void* labels, float* stat_part,
                     int io /*wgnn_io of Y and labels*/, int last_only, float y_mul, float y_add, hipStream_t st);
 int grux_blocks(int B);   // workgroups of launch_grux_fwd = MSE partial pairs it writes when given labels
-// loss and scales {2^k, 2^-k, 2 grad_scale / n} from nblk partial pairs (sum | max) already computed
-int launch_mse_stats_finalize(const float* part, int nblk, int64_t n, float grad_scale, float* loss, float* scales,
-                              hipStream_t st);
 int mse_stats_blocks();
 // exactly one of dY / labels is non-null (labels: dY = (Y - labels) * scales[2], see launch_mse_stats)
 // dGI planes [B*T][ldd] (3H layout) and the n third of dGH alone, dGHn planes [B*T][grux_hn(H)] (dGH's r and z thirds equal dGI's)
 int grux_hn(int H);       // row width (halfs) of the dGHn planes: 8*ceil(H/8)
 int grux_msplit(int H);   // 8*ceil(2H/8): first GEMM row of the dGHn block in the dW_hh product
+// stat_part != null (the partial pairs + tag wgnn_fwd_loss left in the stash): loss[0], scales_out[0..2] are finalised inside
+// the kernel (n_loss = B*T*H, grad_scale as in wgnn_bwd_mse_part); a missing tag gives loss = NaN + WGNN_STATUS_NO_LOSS_STATS
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
                     const float* gates,
-                    const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st);
+                    const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, const float* stat_part,
+                    int64_t n_loss, float grad_scale, float* loss, float* scales_out, unsigned* status, hipStream_t st);
+#define WGNN_STATS_TAG 20261004.0f   // float word behind the MSE partial pairs: "wgnn_fwd_loss wrote these"
 
 int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,
                               unsigned* status, hipStream_t st);
@@ -160,9 +157,6 @@ int launch_split_weight2(const float* W, int R, int C, int transpose, const floa
 int pgemm_nt_np(int N);
 int pgemm_tn_tiles(int Mout, int Nout);   // output tiles per K chunk (sizes the split-K factor)
 size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk);
-int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
-                           float* bias_out, const float* scales, unsigned* status, int msplit, int rows1, int Mgemm,
-                           hipStream_t st);
 // kpart (nullable): pgemm_nt_kpart_floats(M, ldc, Kp) floats of split-K scratch for few-row, long-K products
 size_t pgemm_nt_kpart_floats(int M, int ldc, int Kp);
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
@@ -202,15 +196,27 @@ int launch_gcn1_bwd(int ntiles, int S, const float* A, const float* X, const flo
                     const float* out, const float* dout, float* dW, float* db, float* dX,
                     float* partial, hipStream_t st);
 
-int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh,
-                   float* Y, float* gates /*nullable [B*T][4H]*/, hipStream_t st);
-int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY,
-                   const float* gates, float* dGI, float* dGH, int ldd, hipStream_t st);
+// exact-fp32 recurrences with register-resident W_hh (gru.hip), H <= 128
+//   forward: gates (nullable) = gru_gates_floats() floats of stash in the kernels' own layout; labels + stat_part (nullable):
+//   2 * gru_blocks(B) MSE partials + a tag word; hprev (nullable): [B*T][hq] rows [h_{t-1} | 1 | 0..] for the dW_hh GEMM;
+//   last_only: Y is [B][H] and receives only h_{T-1} * y_mul + y_add
+int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
+                   float* gates, const float* labels, float* stat_part, float* hprev, int hq, int last_only, float y_mul,
+                   float y_add, hipStream_t st);
+//   backward: exactly one of dY / labels; dGI [B*T][ldd] and EITHER dGHn [B*T][gru_hn(H)] (dGH's r and z thirds equal
+//   dGI's) OR the full dGH [B*T][ldd]; stat_part (nullable, with labels): loss[0] is finalised from the forward's partials
+int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
+                   const float* gates, float* dGI, int ldd, float* dGHn, float* dGH, const float* stat_part,
+                   int64_t n_loss, float grad_scale, float* loss, unsigned* status, hipStream_t st);
 bool gru_shape_supported(int H);
+size_t gru_gates_floats(int B, int T, int H);
+int gru_blocks(int B);
+int gru_hn(int H);
+int gru_msplit(int H);
 // small batches (B <= 1024, H <= 128), exact fp32, one window per workgroup with W_hh in registers (gru_small.hip)
 bool gru_small_supported(int B, int H);
 int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                         float* gates, hipStream_t st);
+                         float* gates, float* hprev /*nullable: [B*T][hq] rows [h_{t-1} | 1 | 0..]*/, int hq, hipStream_t st);
 int launch_gru_small_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
                          float* dGI, float* dGH, int ldd, hipStream_t st);
 
@@ -228,7 +234,8 @@ struct FinSeg {                // one split-K weight-gradient product: C[Mout][n
   int kind;                    // 0: nothing to reduce; 1: plain [z][Mout][Nout]; 2: pgemm_tn_kernel's layout
   int T, nNb, ntiles;          // kind 2
   int Mout, Nout, ncols;
-  int msplit, rows1;           // kind 2 with a two-source A operand (pgemm_tn_kernel<.., A2>)
+  int Mgemm;                   // rows of the GEMM that wrote the partials (= Mout unless its A operand had two sources)
+  int msplit, rows1;           // two-source A operand: GEMM row m < rows1 is weight row m, m >= msplit is rows1 + m - msplit
   int scaled;                  // the partials are in units scaled by scales[0]: multiply by scales[1]
   int nblocks;                 // filled in by launch_finish
 };

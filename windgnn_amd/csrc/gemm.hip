@@ -228,32 +228,6 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
     }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splitk, int M, int N,
-                                     float* __restrict__ C, int ldc, int ncols_main, float* __restrict__ bias_out,
-                                     const float* __restrict__ scales) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * N) return;
-  const size_t MN = (size_t)M * N;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-  int z = 0;
-  for (; z + 8 <= splitk; z += 8) {        // 8 independent loads in flight; fixed order => deterministic
-    s0 += partial[(size_t)z * MN + i];
-    s1 += partial[(size_t)(z + 1) * MN + i];
-    s2 += partial[(size_t)(z + 2) * MN + i];
-    s3 += partial[(size_t)(z + 3) * MN + i];
-    s4 += partial[(size_t)(z + 4) * MN + i];
-    s5 += partial[(size_t)(z + 5) * MN + i];
-    s6 += partial[(size_t)(z + 6) * MN + i];
-    s7 += partial[(size_t)(z + 7) * MN + i];
-  }
-  for (; z < splitk; ++z) s0 += partial[(size_t)z * MN + i];
-  float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-  if (scales) s *= scales[1];
-  int m = (int)(i / N), n = (int)(i % N);
-  if (n < ncols_main) C[(size_t)m * ldc + n] = s;
-  else if (bias_out && n == N - 1) bias_out[m] = s;
-}
-
 }  // namespace
 
 // Workgroup tile for an M x N product.  Measured (B = 4096 / 256, S = 34, H = 102): with thousands of tiles the 128 x 128
@@ -301,16 +275,6 @@ int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
   } else {
     PROF_LAUNCH(name, fl, by, st, hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, dim3(256), 0, st, p));
   }
-  WGNN_CHECK_LAUNCH();
-  return WGNN_OK;
-}
-
-int launch_splitk_reduce(const float* partial, int splitk, int M, int N, float* C, int ldc, int ncols_main,
-                         float* bias_out, const float* scales, hipStream_t st) {
-  size_t n = (size_t)M * N;
-  PROF_LAUNCH("splitk_reduce_kernel", (double)n * splitk, 4.0 * n * (splitk + 1), st,
-              hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
-                                 splitk, M, N, C, ldc, ncols_main, bias_out, scales));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }

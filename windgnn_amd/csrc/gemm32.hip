@@ -4,12 +4,12 @@
 // fragments read with wide LDS loads, no per-element bounds code in the main loop.  That needs operands whose rows are
 // 16-byte aligned and whose K extent is padded with finite values: g [B*T][Ip] (ones column at I, zeros after: written by
 // gcn32_fwd), dGI [B*T][Gp] (zero padding written by the recurrences' backward) and zero-padded copies of W_ih / W_ih^T
-// (pad_weight_kernel below, two ~3 us launches per step).  fp32 MFMA sustains 149 TFLOP/s here (tools/mfma_rate.hip);
+// (pad_weight_kernel below; a caller that keeps wgnn_params.prepared never runs it).  fp32 MFMA sustains 149 TFLOP/s here (tools/mfma_rate.hip);
 // the register-staged general kernel of gemm.hip (kept for small B*T and the wide-GRU / CSR paths) reaches 72.
 //
 //   NT  C[M][N] = A[M][Kp] . Bp[N][Kp]^T      GI = [g|1] [W_ih|b_ih]^T,   dg = dGI (W_ih^T)^T
 //   TN  P[z][Mo][No] = sum_k A[k][m] B[k][n]  dW_ih|db_ih = dGI^T [g|1], dW_hh|db_hh = dGH^T [Hprev|1]
-//                                              (split-K, reduced by splitk_reduce_kernel)
+//                                              (split-K, reduced by finish.hip)
 #include <string>
 
 #include "common.h"
@@ -121,11 +121,15 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
 // windows.  The DMA image is linear, so the 16 pad floats of a row are written too (with the row's first chunk).
 constexpr int T_BM = 320, T_BK = 32;
 
+// A2 != null: GEMM columns m >= msplit of the A operand are column m - msplit of A2 (row stride lda2; msplit a multiple of
+// 4, so no 16-byte chunk straddles the two sources).  Used for dW_hh = [dGI_r | dGI_z | dGH_n]^T [Hprev|1]: the BPTT kernel
+// stores the n third of dGH only (its r and z thirds equal dGI's).
 template <int T16>
 __global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __restrict__ A, int lda,
                                                                const float* __restrict__ B, int ldb, int K, int kchunk,
                                                                int splitk, float* __restrict__ P, int Mo, int No,
-                                                               int nNb, int ntiles) {
+                                                               int nNb, int ntiles, const float* __restrict__ A2,
+                                                               int lda2, int msplit) {
   constexpr int WN = 16 * T16, BN = 2 * WN;
   constexpr int PA = T_BM + 16, PB = BN + 16;                     // LDS row pitches (floats)
   constexpr int A_BYTES = T_BK * PA * 4, STAGE = A_BYTES + T_BK * PB * 4;
@@ -150,8 +154,8 @@ __global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __
 
   // DMA plan: piece p of the stage image = bytes [1024 p, 1024 p + 1024); lane -> (row, column) through the pitch
   int roff[NIT], coff[NIT], dst[NIT];     // row within the stage, column offset in floats (already + m0 / n0)
-  bool on[NIT], isA[NIT];
-  const int wa = min(T_BM, lda - m0), wb = min(BN, ldb - n0);      // columns that exist in memory
+  bool on[NIT], isA[NIT], isA2[NIT];
+  const int wa = min(T_BM, (A2 ? msplit + lda2 : lda) - m0), wb = min(BN, ldb - n0);      // columns that exist in memory
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int p = wave + G_WAVES * it;
@@ -164,6 +168,8 @@ __global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __
     const int row = f / pitch, col = f % pitch;
     roff[it] = row;
     coff[it] = isA[it] ? m0 + (col < wa ? col : 0) : n0 + (col < wb ? col : 0);
+    isA2[it] = isA[it] && A2 && coff[it] >= msplit;
+    if (isA2[it]) coff[it] -= msplit;
     dst[it] = (isA[it] ? 0 : A_BYTES) + q * 1024;
   }
   auto dma_stage = [&](char* st, int k0) {
@@ -171,7 +177,8 @@ __global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __
     for (int it = 0; it < NIT; ++it)
       if (on[it]) {
         const int k = min(k0 + roff[it], K - 1);                   // rows past the chunk are zeroed below
-        const float* src = isA[it] ? A + (size_t)k * lda + coff[it] : B + (size_t)k * ldb + coff[it];
+        const float* src = isA2[it] ? A2 + (size_t)k * lda2 + coff[it]
+                                    : (isA[it] ? A + (size_t)k * lda + coff[it] : B + (size_t)k * ldb + coff[it]);
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + dst[it]), 16, 0, 0);
       }
   };
@@ -240,22 +247,6 @@ __global__ void pad_weight_kernel(const float* __restrict__ W, int R, int C, int
   out[idx] = v;
 }
 
-// Hp[B*T][ld] = [Hprev | 1 | 0...]: row (b, t) = Y row (b, t-1), zero at t = 0 -- the B operand of dW_hh|db_hh = dGH^T [Hprev|1]
-// with 16-byte aligned rows (Y's rows are H floats long).  One thread per 4 output floats.
-__global__ void hprev_pad_kernel(const float* __restrict__ Y, size_t BT, int T, int H, float* __restrict__ out, int ld) {
-  const int q4 = ld / 4;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= BT * q4) return;
-  const size_t bt = idx / q4;
-  const int c = 4 * (int)(idx % q4);
-  const bool live = (bt % T) != 0;
-  const float* src = Y + (live ? bt - 1 : 0) * H;
-  f32x4 v;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = c + j < H ? (live ? src[c + j] : 0.f) : (c + j == H ? 1.f : 0.f);
-  *(f32x4*)(out + bt * ld + c) = v;
-}
-
 // big form: N slices of 64 T32 columns (T32 <= 7: 2 x 56 KB of B + 2 x 16 KB of A fill the CU's LDS);
 // small form: N slices of 32 NW columns (NW <= 14 waves)
 void nt_shape(int N, bool big, int& nsl, int& T) {
@@ -291,7 +282,7 @@ void tn_shape(int No, int& nNb, int& T) {
 
 template <int T16>
 int launch_tn_t(const float* A, int lda, const float* B, int ldb, int K, int splitk, float* P, int Mo, int No, int nNb,
-                hipStream_t st) {
+                const float* A2, int lda2, int msplit, hipStream_t st) {
   const int ntiles = cdiv_i(Mo, T_BM) * nNb;
   const int kchunk = cdiv_i(cdiv_i(K, splitk), T_BK) * T_BK;
   const size_t smem = 2 * (size_t)T_BK * (T_BM + 16 + 32 * T16 + 16) * 4;
@@ -303,7 +294,7 @@ int launch_tn_t(const float* A, int lda, const float* B, int ldb, int K, int spl
   const int grid = cdiv_i(splitk, 8) * 8 * ntiles;
   PROF_LAUNCH(name.c_str(), fl, by, st,
               hipLaunchKernelGGL(gemm32_tn_kernel<T16>, dim3(grid), dim3(64 * G_WAVES), smem, st, A, lda, B, ldb, K,
-                                 kchunk, splitk, P, Mo, No, nNb, ntiles));
+                                 kchunk, splitk, P, Mo, No, nNb, ntiles, A2, lda2, msplit));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -362,32 +353,23 @@ int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, fl
 }
 
 // Workgroup tiles of the split-K product (for the split-K choice) and the product itself:
-// P[z][Mo][No] = sum over K chunk z of A[k][m] B[k][n]; rows of A and B 16-byte aligned; reduce with launch_splitk_reduce.
+// P[z][Mo][No] = sum over K chunk z of A[k][m] B[k][n]; rows of A and B 16-byte aligned; reduced by finish.hip (plain [z][Mo][No] layout).
 int gemm32_tn_tiles(int Mo, int No) {
   int nNb, T;
   tn_shape(No, nNb, T);
   return cdiv_i(Mo, T_BM) * nNb;
 }
 int launch_gemm32_tn(const float* A, int lda, const float* B, int ldb, int K, int splitk, float* P, int Mo, int No,
-                     hipStream_t st) {
+                     const float* A2, int lda2, int msplit, hipStream_t st) {
   int nNb, T;
   tn_shape(No, nNb, T);
   if (lda % 4 != 0 || ldb % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || splitk < 1) return WGNN_ERR_SHAPE;
+  if (A2 && (lda2 % 4 != 0 || msplit % 4 != 0 || msplit > lda || ((uintptr_t)A2 & 15))) return WGNN_ERR_SHAPE;
   switch (T) {
 #define TN_CASE(t) \
-  case t: return launch_tn_t<t>(A, lda, B, ldb, K, splitk, P, Mo, No, nNb, st);
+  case t: return launch_tn_t<t>(A, lda, B, ldb, K, splitk, P, Mo, No, nNb, A2, lda2, msplit, st);
     TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(7)
 #undef TN_CASE
   }
   return WGNN_ERR_SHAPE;
-}
-
-int launch_hprev_pad(const float* Y, int B, int T, int H, float* out, int ld, hipStream_t st) {
-  const size_t BT = (size_t)B * T, n = BT * ld;
-  if (ld % 4 != 0) return WGNN_ERR_SHAPE;
-  PROF_LAUNCH("hprev_pad_kernel", 0.0, 4.0 * (n + (double)BT * H), st,
-              hipLaunchKernelGGL(hprev_pad_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, Y, BT, T, H,
-                                 out, ld));
-  WGNN_CHECK_LAUNCH();
-  return WGNN_OK;
 }

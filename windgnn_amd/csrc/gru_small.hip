@@ -22,7 +22,20 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
                                                                       const float* __restrict__ Whh,
                                                                       const float* __restrict__ bhh,
                                                                       float* __restrict__ Y, float* __restrict__ gates,
-                                                                      int stage_w) {
+                                                                      int stage_w, float* __restrict__ hprev, int hq) {
+  // hprev (nullable): rows [h_{t-1} | 1 | 0..] of width hq with 16-byte aligned rows, the B operand of the dW_hh GEMM
+  // (gemm32.hip) -- written here instead of by a pass of its own over Y
+  if (hprev) {
+    for (int wdw = 0; wdw < WPB; ++wdw) {
+      const int b = blockIdx.x * WPB + wdw;
+      if (b >= B) break;
+      for (int q = threadIdx.x; q < T * (hq - H); q += blockDim.x) {
+        const int c = H + q % (hq - H);
+        hprev[((size_t)b * T + q / (hq - H)) * hq + c] = c == H ? 1.f : 0.f;
+      }
+      for (int c = threadIdx.x; c < H; c += blockDim.x) hprev[(size_t)b * T * hq + c] = 0.f;
+    }
+  }
   __shared__ __attribute__((aligned(16))) float hs[WPB][HMAX];       // h_{t-1}, zero beyond H
   __shared__ float ghs[WPB][3 * HMAX];                               // W_hh h + b_hh, gate-major with stride HMAX
   const int i = threadIdx.x;
@@ -108,7 +121,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
         if (b < B) {
           const size_t bt = (size_t)b * T + t;
           Y[bt * H + j] = hnew;
-          if (gates)   // one 16-byte record (r, z, n, gh_n) per element, [bt][j][4] (as gru.hip)
+          if (hprev && t + 1 < T) hprev[(bt + 1) * hq + j] = hnew;
+          if (gates)   // one 16-byte record (r, z, n, gh_n) per element, [bt][j][4]
             *(f32x4*)(gates + (bt * H + j) * 4) = f32x4{rg, zg, ng, ghn};
         }
       }
@@ -263,28 +277,29 @@ bool gru_small_supported(int B, int H) { return H >= 1 && H <= 128 && B <= 1024;
 
 template <int HMAX>
 static int launch_small_fwd_t(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                              float* gates, hipStream_t st) {
+                              float* gates, float* hprev, int hq, hipStream_t st) {
   const size_t wbytes = (size_t)3 * H * H * sizeof(float);
   const int stage_w = wbytes <= 140 * 1024;
   const size_t smem = stage_w ? wbytes : 0;
   static std::atomic<unsigned long long> done{0};
   if (ensure_dyn_smem((const void*)gru_small_fwd_kernel<HMAX, 1>, 140 * 1024, done) != WGNN_OK) return WGNN_ERR_HIP;
   hipLaunchKernelGGL((gru_small_fwd_kernel<HMAX, 1>), dim3(B), dim3(cdiv_i(3 * H, 64) * 64), smem, st, B, T, H, GI, ldgi,
-                     Whh, bhh, Y, gates, stage_w);
+                     Whh, bhh, Y, gates, stage_w, hprev, hq);
   return WGNN_OK;
 }
 
 int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                         float* gates, hipStream_t st) {
+                         float* gates, float* hprev, int hq, hipStream_t st) {
   if (!gru_small_supported(B, H)) return WGNN_ERR_UNSUPPORTED;
+  if (hprev && (hq < H + 1 || hq % 4 != 0)) return WGNN_ERR_SHAPE;
   const double bt = (double)B * T;
   int rc = WGNN_OK;
-  PROF_LAUNCH("gru_small_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0)), st,
-              rc = H <= 32   ? launch_small_fwd_t<32>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st)
-                   : H <= 64 ? launch_small_fwd_t<64>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st)
-                   : H <= 96 ? launch_small_fwd_t<96>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st)
-                   : H <= 112 ? launch_small_fwd_t<112>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st)
-                              : launch_small_fwd_t<128>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, st));
+  PROF_LAUNCH("gru_small_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0) + (hprev ? hq : 0)), st,
+              rc = H <= 32   ? launch_small_fwd_t<32>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st)
+                   : H <= 64 ? launch_small_fwd_t<64>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st)
+                   : H <= 96 ? launch_small_fwd_t<96>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st)
+                   : H <= 112 ? launch_small_fwd_t<112>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st)
+                              : launch_small_fwd_t<128>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st));
   if (rc != WGNN_OK) return rc;
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;

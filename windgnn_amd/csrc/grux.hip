@@ -111,6 +111,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   if (threadIdx.x < 2 * MB)   // ones column of both buffers' hi planes (W_hh fragments are 0 there)
     hbuf[(threadIdx.x / MB) * 2 * MB * HS + (threadIdx.x % MB) * HS + H] = (_Float16)1.f;
 
+  // tag behind the MSE partial pairs: set by wgnn_fwd_loss, cleared by a plain wgnn_fwd on the same stash, checked by the
+  // BPTT kernel when the caller claims (part bit 8) that the statistics of THESE labels are in the stash
+  if (stat_part && blockIdx.x == 0 && threadIdx.x == 0) stat_part[2 * gridDim.x] = Lab ? WGNN_STATS_TAG : 0.f;
   if (yp_hi && blockIdx.x == 0 && threadIdx.x < HP) {   // row B*T: what [Hprev | 1] looks like at t = 0
     yp_hi[(size_t)B * T * HP + threadIdx.x] = (_Float16)(threadIdx.x == H ? 1.f : 0.f);
     yp_lo[(size_t)B * T * HP + threadIdx.x] = (_Float16)0.f;
@@ -387,8 +390,55 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
                                                             const float* __restrict__ scales,
                                                             _Float16* __restrict__ dGI_hi, _Float16* __restrict__ dGI_lo,
                                                             int ldd, _Float16* __restrict__ dGN_hi,
-                                                            _Float16* __restrict__ dGN_lo) {
+                                                            _Float16* __restrict__ dGN_lo,
+                                                            const float* __restrict__ stat_part, int nstat, float inv_n,
+                                                            float coef_in, float* __restrict__ loss_out,
+                                                            float* __restrict__ scales_out, unsigned* status) {
   constexpr int DS = 32 * KSB + 8;
+  // stat_part != null (wgnn_bwd_mse_part(.. | 8) after wgnn_fwd_loss): the loss, the power-of-two range scale and the dY
+  // coefficient are finalised HERE from the forward recurrence's nstat partial pairs (sum | max), by every workgroup for
+  // itself (2 nstat floats out of L2; the max is order-independent, so all workgroups agree on the scale), instead of in a
+  // launch of their own; workgroup 0 publishes loss and scales for the kernels that follow.
+  float s_fin = 1.f, c_fin = coef_in;
+  if (stat_part) {
+    __shared__ float sred[2][NTHREADS / 64];
+    float a = 0.f, m = 0.f;
+    for (int i = threadIdx.x; i < nstat; i += NTHREADS) {
+      a += stat_part[i];
+      m = fmaxf(m, stat_part[nstat + i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      m = fmaxf(m, __shfl_xor(m, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      sred[0][threadIdx.x >> 6] = a;
+      sred[1][threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    a = 0.f;
+    m = 0.f;
+#pragma unroll
+    for (int w = 0; w < NTHREADS / 64; ++w) {
+      a += sred[0][w];
+      m = fmaxf(m, sred[1][w]);
+    }
+    const bool tagged = stat_part[2 * nstat] == WGNN_STATS_TAG;
+    m *= fabsf(coef_in);
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);
+      s_fin = ldexpf(1.f, 1 - e);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      loss_out[0] = tagged ? a * inv_n : __builtin_nanf("");     // no statistics of these labels in the stash: loud, not stale
+      scales_out[0] = s_fin;
+      scales_out[1] = 1.f / s_fin;
+      scales_out[2] = coef_in;
+      if (!tagged && status) atomicOr(status, WGNN_STATUS_NO_LOSS_STATS);
+    }
+  }
   // per step parity: dgh hi | dgh lo (padded layout, also the MFMA A operand) | dgi hi | dgi lo (3H layout); columns
   // never written (K padding, the tail of the dnr block) stay zero.  Double-buffered by step parity (kept with
   // the second barrier below: dropping that barrier was slower)
@@ -402,10 +452,10 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   const int jc = jv ? j : H - 1;
   const int b0 = blockIdx.x * MB;
   const int MS = 8 * ((2 * H + 7) / 8), HN = 8 * ((H + 7) / 8);
-  const float s_in = scales ? scales[0] : 1.f;
+  const float s_in = stat_part ? s_fin : (scales ? scales[0] : 1.f);
   // fused MSE (wgnn_bwd_mse_part): dY is not materialised, dY[b,t] = (Y[b,t] - L[b,t]) * scales[2] is formed here;
   // Y[b,t] is the h_prev this kernel loaded for step t+1, so only L is read in dY's place.
-  const float coef = Lab ? scales[2] : 1.f;
+  const float coef = stat_part ? c_fin : (Lab ? scales[2] : 1.f);
 
   Frag WT[KSB];                                    // B operand: W_hh[row(k)][j], k = 32ks + 8g + jj in the padded layout
 #pragma unroll
@@ -674,7 +724,11 @@ int grux_msplit(int H) { return 8 * cdiv_i(2 * H, 8); }
 
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
                     const float* gates,
-                    const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, hipStream_t st) {
+                    const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, const float* stat_part,
+                    int64_t n_loss, float grad_scale, float* loss, float* scales_out, unsigned* status, hipStream_t st) {
+  // stat_part != null: loss and scales are finalised inside the kernel (once a separate one-block launch)
+  const int nstat = grux_blocks(B);
+  const float inv_n = stat_part ? 1.0f / (float)n_loss : 0.f, coef_in = stat_part ? 2.0f * grad_scale / (float)n_loss : 0.f;
   _Float16* ih = (_Float16*)dGI_planes;
   _Float16* il = ih + (size_t)B * T * ldd;
   _Float16* nh = (_Float16*)dGHn_planes;
@@ -688,7 +742,7 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
 #define BLAUNCH(K, X3V, IOV, NAME, BYTES)                                                                         \
   PROF_LAUNCH(NAME, fl, BYTES, st,                                                                                \
               hipLaunchKernelGGL((grux_bwd_kernel<K, X3V, IOV>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, io, \
-                                 gates, scales, ih, il, ldd, nh, nl))
+                                 gates, scales, ih, il, ldd, nh, nl, stat_part, nstat, inv_n, coef_in, loss, scales_out, status))
 #define BCASE(K)                                                                                                  \
   if (x3 && !io) BLAUNCH(K, true, false, "grux_bwd_kernel<" #K ">", by);                                          \
   else if (x3) BLAUNCH(K, true, true, "grux_bwd_kernel<" #K ">", by);                                             \

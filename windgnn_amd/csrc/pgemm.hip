@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
 
   // Partials are stored in the accumulators' own layout, [z][tile][wave][i][j][lane][4]: every store is a
   // full 1 KB wave-instruction (row-major P would be 64-byte segments, 4x the store instructions);
-  // tn_reduce_kernel undoes the permutation while it sums over z.
+  // finish.hip (seg_tn) undoes the permutation while it sums over z.
   float* P = partial + (((size_t)z * gridDim.y + blockIdx.y) * TN_WAVES + wave) * (5 * T * 256) + lane * 4;
 #pragma unroll
   for (int i = 0; i < 5; ++i)
@@ -363,59 +363,6 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
     for (int j = 0; j < T; ++j) {
       *(f32x4*)(P + (i * T + j) * 256) = acc[i][j];
     }
-}
-
-// C[m][n] (and the bias column) = scale * sum_z partial[z][...] for partials in pgemm_tn_kernel's layout; the
-// summation tree over z is fixed, so the result is deterministic.  Four threads (z phases) per accumulator quad.
-__global__ void tn_reduce_kernel(const float* __restrict__ partial, int splitk, int T, int nNb, int ntiles, int Mout,
-                                 int Nout, float* __restrict__ C, int ldc, int ncols_main,
-                                 float* __restrict__ bias_out, const float* __restrict__ scales,
-                                 unsigned* status, int msplit, int rows1) {
-  // msplit > 0: GEMM row m < rows1 is output row m, GEMM row m >= msplit is output row rows1 + (m - msplit),
-  // rows in between are padding (the two-source A operand of pgemm_tn_kernel<.., A2 = true>)
-  const size_t slab4 = (size_t)ntiles * TN_WAVES * 5 * T * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 quads x 4 z phases per block
-  const size_t q = (size_t)blockIdx.x * 64 + tx;                     // slab4 is a multiple of 64
-  const f32x4* src = (const f32x4*)partial + q;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  int z = ty;
-  for (; z + 12 < splitk; z += 16) {       // 4 independent 16-byte loads in flight per thread
-    s0 += src[(size_t)z * slab4];
-    s1 += src[(size_t)(z + 4) * slab4];
-    s2 += src[(size_t)(z + 8) * slab4];
-    s3 += src[(size_t)(z + 12) * slab4];
-  }
-  for (; z < splitk; z += 4) s0 += src[(size_t)z * slab4];
-  __shared__ f32x4 red[4][64];
-  red[ty][tx] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (ty != 0) return;
-  f32x4 s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-  if (scales) s *= scales[1];
-  size_t t = q;
-  const int lane = (int)(t % 64); t /= 64;
-  const int j = (int)(t % T); t /= T;
-  const int i = (int)(t % 5); t /= 5;
-  const int wave = (int)(t % TN_WAVES);
-  const int tile = (int)(t / TN_WAVES);
-  const int mb = tile / nNb, nb = tile % nNb, wm = wave & 3, wn = wave >> 2;
-  const int n = nb * 32 * T + 16 * (T * wn + j) + (lane & 15);
-  const int m0 = mb * TN_BM + 80 * wm + 16 * i + 4 * (lane >> 4);
-  if (n >= Nout) return;
-  bool bad = false;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int m = m0 + r;
-    if (msplit > 0) {
-      if (m >= msplit) m = rows1 + (m - msplit);
-      else if (m >= rows1) continue;
-    }
-    if (m >= Mout) continue;
-    bad |= !(__builtin_fabsf(s[r]) <= 3.0e38f);                      // inf / NaN in a final gradient
-    if (n < ncols_main) C[(size_t)m * ldc + n] = s[r];
-    else if (bias_out && n == Nout - 1) bias_out[m] = s[r];
-  }
-  report_status(status, bad, WGNN_STATUS_GRAD_NONFINITE);
 }
 
 // Planes of O[Rp][Cp] (O[r][c] = transpose ? W[c][r] : W[r][c]; optional extra column `bias_col`
@@ -607,24 +554,7 @@ size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk) {
   return (size_t)splitk * cdiv_i(Mout, TN_BM) * nNb * TN_WAVES * 5 * T * 256;
 }
 
-// C[Mout][ldc] columns [0, ncols_main) and bias_out (column Nout-1) = scales[1] * sum over z of launch_pgemm_tn's partials.
-int launch_pgemm_tn_reduce(const float* partial, int splitk, int Mout, int Nout, float* C, int ldc, int ncols_main,
-                           float* bias_out, const float* scales, unsigned* status, int msplit, int rows1, int Mgemm,
-                           hipStream_t st) {
-  // Mout: rows of C; Mgemm: rows of the GEMM that wrote the partials (= Mout unless the A operand had two sources)
-  int nNb, T;
-  tn_shape(Nout, nNb, T);
-  const int ntiles = cdiv_i(Mgemm, TN_BM) * nNb;
-  const size_t slab4 = (size_t)ntiles * TN_WAVES * 5 * T * 64;
-  PROF_LAUNCH("tn_reduce_kernel", (double)slab4 * 4 * splitk, 16.0 * slab4 * splitk + 4.0 * Mout * Nout, st,
-              hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(slab4 / 64)), dim3(256), 0, st, partial,
-                                 splitk, T, nNb, ntiles, Mout, Nout, C, ldc, ncols_main, bias_out, scales, status,
-                                 msplit, rows1));
-  WGNN_CHECK_LAUNCH();
-  return WGNN_OK;
-}
-
-// partial (layout private to this file, pgemm_tn_partial_floats floats) = per-K-chunk sums of A[k][m] B[k][n].
+// partial (pgemm_tn_kernel's own layout, read by finish.hip; pgemm_tn_partial_floats floats) = per-K-chunk sums of A[k][m] B[k][n].
 // A planes [K][lda], B planes [K][ldb].
 // shift_T > 0: B row k is taken from row k-1, and from the extra row K (which the producer fills with what the
 // operand looks like at a window start) where k % shift_T == 0.

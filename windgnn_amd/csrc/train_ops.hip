@@ -188,14 +188,6 @@ int launch_mse_stats(const float* Y, const float* L, int64_t n, float grad_scale
 
 int mse_stats_blocks() { return MSE_BLOCKS; }
 
-int launch_mse_stats_finalize(const float* part, int nblk, int64_t n, float grad_scale, float* loss, float* scales,
-                              hipStream_t st) {
-  hipLaunchKernelGGL(mse_stats_finalize_kernel, dim3(1), dim3(64), 0, st, part, nblk, 1.0f / (float)n,
-                     2.0f * grad_scale / (float)n, loss, scales);
-  WGNN_CHECK_LAUNCH();
-  return WGNN_OK;
-}
-
 int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=448 floats*/, hipStream_t st) {
   PROF_LAUNCH("amax_partial_kernel", (double)n, 4.0 * n, st,
               hipLaunchKernelGGL(amax_partial_kernel, dim3(448), dim3(256), 0, st, x, n, part));

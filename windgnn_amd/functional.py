@@ -104,7 +104,9 @@ class _Workspace:
 
 _STATUS_TEXT = {1: "a graph-convolution pre-activation left fp16's range (|x| > 65504) or was NaN",
                 2: "a GRU weight or bias lies outside fp16's range",
-                4: "a gradient came out inf / NaN"}
+                4: "a gradient came out inf / NaN",
+                8: "wgnn_bwd_mse_part(part | 8) ran on a stash whose last forward was not wgnn_fwd_loss: the loss is NaN "
+                   "and the gradients are not to be used"}
 
 
 def check_range_status(device=None) -> None:
