@@ -124,10 +124,15 @@ class TrainStep:
             self.exchange.finish(work, gs)      # loss: sum of the weighted shard means = the big-batch mean
             finish_step(d, self.p_views, self.g_views, 0, self._adam(), pre, self.device)      # src/main.py:80
         else:
+            # One rank: BPTT, then the dg GEMM + GCN backward, and the weight-gradient GEMMs LAST, so that wgnn_finish reads
+            # their split-K partial sums (115 MB at B = 4096) while they still sit in the Infinity Cache; deferring them
+            # across the dg GEMM and the GCN backward (0.8 GB of traffic) had them come back from HBM (finish 35 us)
             Y, stash, d = self._forward(A, X, L)
-            gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0, part=7 | 8 | DEFER,
-                                     prepared=self._prepared)
-            finish_step(d, self.p_views, self.g_views, 6, self._adam(), self._prepared, self.device)   # :79 tail + :80
+            pre = self._prepared
+            for part in (1 | 8, 2, 4):
+                gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0, part=part | DEFER,
+                                         prepared=pre)
+            finish_step(d, self.p_views, self.g_views, 6, self._adam(), pre, self.device)              # :79 tail + :80
         if self.check_every and self.model.math != _lib.MATH_F32 and self.steps % self.check_every == 0:
             self.check()
         return loss, Y
