@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 
 S, T, F, H = 34, 24, 13, 102
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x3g": 2500.0, "f16": 2500.0}
+DTYPE_LABEL = {"f32": "f32", "f16x3": "f16x3(split-fp32)", "f16": "f16",
+               "f16x3g": "f16x3g(split-fp32 forward + recurrences; gate gradients as one fp16 plane in the backward GEMMs)"}
 # which roofline bounds each kernel (DESIGN.md "Kernels")
 BOUND_HBM_PREFIXES = ("mse_", "adam_", "finish_", "amax_", "splitk_reduce", "tn_reduce", "split_weight", "gcn_partial", "csr_", "gru_cell")
 
@@ -185,7 +187,7 @@ def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
     torch.cuda.synchronize()
     dt = time.perf_counter() - s0
     tr.check()
-    out = {"dtype": {"f32": "f32", "f16x3": "f16x3(split-fp32)", "f16": "f16"}[math] + ("" if io == "fp32" else " math, %s I/O" % io),
+    out = {"dtype": DTYPE_LABEL[math] + ("" if io == "fp32" else " math, %s I/O" % io),
            "value": round(B * nsteps / dt, 1), "unit": "windows/s", "ms_per_step": round(1e3 * dt / nsteps, 4),
            "steps": nsteps, "batch": B, "note": note}
     if forward:
@@ -209,7 +211,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU (weak scaling); default 4096 (128 for c5)")
-    ap.add_argument("--math", default="f16x3", choices=["f32", "f16x3", "f16"])
+    ap.add_argument("--math", default="f16x3g", choices=["f32", "f16x3", "f16x3g", "f16"],
+                    help="f16x3g (default): f16x3 whose backward gate gradients travel as ONE fp16 plane (include/windgnn.h, "
+                         "WGNN_MATH_F16X3G); f16x3: all products three-pass split fp16; f32: exact fp32; f16: one-pass fp16")
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
                     help="c3: 34 stations, the headline config; c5: 4096-station k-NN CSR stress config")
     ap.add_argument("--io", default="fp32", choices=["fp32", "fp16", "bf16"],
@@ -247,7 +251,7 @@ def main():
             traffic, traffic_src = measure_traffic_live(args)
         if not traffic:
             why = traffic_src
-            traffic, traffic_src = (({}, None) if args.workload != "c3" or args.math != "f16x3" or args.io != "fp32"
+            traffic, traffic_src = (({}, None) if args.workload != "c3" or args.math != "f16x3g" or args.io != "fp32"
                                     else committed_traffic())
             if traffic_src:
                 traffic_src = "committed file %s (%s)" % (traffic_src, why or "--no-traffic")
@@ -333,7 +337,7 @@ def main():
         avg_s = d["ms"] / d["launches"] * 1e-3
         # which roofline binds this kernel: time its ALGORITHMIC bytes need at the HBM peak vs the time its
         # algorithmic flops need at the MFMA peak (f16x3 issues 3 MFMA passes per product => peak / 3)
-        eff_peak = MFMA_PEAK_TFLOPS[args.math] / (3.0 if args.math == "f16x3" else 1.0)
+        eff_peak = MFMA_PEAK_TFLOPS[args.math] / (3.0 if args.math in ("f16x3", "f16x3g") else 1.0)
         t_hbm = d["bytes"] / (HBM_PEAK_GBS * 1e9)
         t_mfma = d["flops"] / (eff_peak * 1e12)
         bound = "hbm" if (d["name"].startswith(BOUND_HBM_PREFIXES) or t_hbm >= t_mfma) else "mfma"
@@ -359,7 +363,9 @@ def main():
         gemms = [r for r in recs if r["name"].startswith(("pgemm_", "gemm_f32")) and r["flops"] > 0]
         if gemms:
             gk = gemms[0]
-            passes = 3.0 if (args.math == "f16x3" and gk["name"].startswith("pgemm_")) else 1.0
+            passes = 1.0
+            if gk["name"].startswith("pgemm_") and args.math in ("f16x3", "f16x3g"):
+                passes = 2.0 if gk["name"].endswith(",x2>") else 3.0
             peak_k = MFMA_PEAK_TFLOPS["f32" if gk["name"].startswith("gemm_f32") else args.math]
             tf = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
             mfma = {"kernel": gk["name"], "algorithmic_TFLOPs": round(tf, 1), "issued_TFLOPs": round(tf * passes, 1),
@@ -382,11 +388,15 @@ def main():
                    "hbm_frac": round(fwd_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
                    "windows_per_s": round(B / fwd_s, 1)}
         # ---- secondaries on the same box, each a labelled dtype of its own (never folded into `value`):
+        #   f16x3_strict         the headline workload with every product three-pass (WGNN_MATH_F16X3)
         #   exact_f32            the headline workload in WGNN_MATH_F32 (bitwise fp32 fmaf chains, fp32-input MFMA)
         #   c1_f32_b256          BASELINE configs[1]: B = 256, exact fp32 (the parity config)
         #   c2_f16_bf16io_b4096  BASELINE configs[2] literally: one-pass fp16 MFMA, bf16 X / Y / labels, B = 4096
-        if world == 1 and args.math == "f16x3" and args.workload == "c3" and not args.no_secondary and args.io == "fp32" \
+        if world == 1 and args.math == "f16x3g" and args.workload == "c3" and not args.no_secondary and args.io == "fp32" \
                 and args.batch is None:
+            extra["f16x3_strict"] = secondary_config("f16x3", "fp32", B, A, dev, max(5, min(args.steps, 30)),
+                                                     "same workload and step, WGNN_MATH_F16X3: every product three-pass "
+                                                     "split fp16, gradients ~1e-6 of max against the fp64 oracle")
             secondary = secondary_config("f32", "fp32", B, A, dev, max(5, min(args.steps, 30)),
                                          "same workload and step, WGNN_MATH_F32 (fp32-input MFMA, bitwise fp32 fmaf chains)")
             extra["c1_f32_b256"] = secondary_config("f32", "fp32", 256, A, dev, max(10, min(2 * args.steps, 60)),
@@ -408,7 +418,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16x3": "f16x3(split-fp32)", "f16": "f16"}[args.math] +
+            "dtype": DTYPE_LABEL[args.math] +
                      ("" if args.io == "fp32" else " math, %s I/O" % args.io),
             "data": "synthetic",
             "config": {"workload": "S=%d stations%s, T=24, F=13, H=%d, B=%d windows/GPU; step = forward + MSE + "
@@ -422,6 +432,7 @@ def main():
             "path": path,
             "mfma": mfma,
             "forward": forward,
+            "f16x3_strict": extra.get("f16x3_strict"),
             "exact_f32": secondary,
             "c1_f32_b256": extra.get("c1_f32_b256"),
             "c2_f16_bf16io_b4096": extra.get("c2_f16_bf16io_b4096"),

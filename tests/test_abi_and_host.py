@@ -41,6 +41,8 @@ def test_dims_validation_no_gpu_needed():
     c5 = L.Dims(128, 24, 4096, 13, 12288, 0, 1, 73000)        # BASELINE configs[4], one GPU's shard
     assert lib.wgnn_workspace_bytes(ctypes.byref(c5)) > (1 << 32) and lib.wgnn_stash_bytes(ctypes.byref(c5)) > 0
     assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4, 24, 34, 13, 400, 1, 0, 0))) > 0   # wide GRU: general path
+    assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4096, 24, 34, 13, 102, L.MATH_F16X3G, 0, 0))) > 0   # bench.py's mode
+    assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4, 24, 34, 13, 102, 4, 0, 0))) == 0                # unknown math mode
     # 16-bit X / Y / labels (wgnn_io): only with the fp16-plane kernels (math f16x3 / f16, dense adjacency, H <= 127)
     assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4, 24, 34, 13, 102, 1, 0, 0, L.IO_BF16))) > 0
     assert lib.wgnn_workspace_bytes(ctypes.byref(L.Dims(4, 24, 34, 13, 102, 2, 0, 0, L.IO_F16))) > 0

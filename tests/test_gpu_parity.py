@@ -67,7 +67,7 @@ def test_inference_no_grad_matches(golden):
     assert max_abs(out.cpu().reshape(golden["Y"].shape), golden["Y"]) <= Y_TOL
 
 
-@pytest.mark.parametrize("math", ["f32", "f16x3"])
+@pytest.mark.parametrize("math", ["f32", "f16x3", "f16x3g"])
 @pytest.mark.parametrize("S,T,B,H", [(34, 24, 256, 102), (7, 12, 32, 21), (34, 24, 37, 102), (5, 3, 17, 9),
                                      (16, 4, 16, 48), (48, 2, 3, 33), (1, 1, 1, 1),
                                      (64, 3, 2, 127), (33, 1, 19, 100), (2, 7, 33, 6), (34, 24, 1100, 102)])
@@ -258,7 +258,7 @@ def test_predict_last_matches_reference_readout():
     assert max_abs(out, ref) <= 1e-4 * (wmax - wmin)
 
 
-@pytest.mark.parametrize("math", ["f16x3", "f16"])
+@pytest.mark.parametrize("math", ["f16x3", "f16x3g", "f16"])
 def test_full_size_properties_B4096(math):
     """BASELINE's full size (S=34, T=24, B=4096, H=102) in the fp32-grade mode (f16x3, configs[3]'s per-GPU shard)
     and in the 16-bit mode (f16, configs[2]): properties that need no oracle run, plus an oracle-checked slice.
@@ -271,7 +271,10 @@ def test_full_size_properties_B4096(math):
     import numpy as np, os
     from conftest import GOLDEN
     dev = _dev()
-    y_tol, g_tol = (Y_TOL, G_TOL) if math == "f16x3" else (F16_Y_TOL, F16_G_TOL)
+    # f16x3g: dY here is pure zero-mean noise, i.e. every gradient is a fully cancelling sum -- the worst case for the
+    # single-plane gate gradients (relative 2^-12 per dGI element, nothing averages out): observed 3.7e-4 of max, bound 1e-3;
+    # with the MSE loss the same mode is held to G_TOL (test_against_oracle_random, B = 256 and 1100: observed 6e-6)
+    y_tol, g_tol = {"f16x3": (Y_TOL, G_TOL), "f16x3g": (Y_TOL, 1e-3), "f16": (F16_Y_TOL, F16_G_TOL)}[math]
     S, T, B, H = 34, 24, 4096, 102
     A = torch.from_numpy(np.load(os.path.join(GOLDEN, "graph_7_34.npz"))["A34"]).float()
     g = torch.Generator().manual_seed(99)
@@ -1053,7 +1056,7 @@ def test_raw_entry_points_refuse_strided_tensors_and_trainstep_copies_them():
     assert abs(float(l1) - float(fx["loss"])) <= 1e-5
 
 
-@pytest.mark.parametrize("math", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("math", ["f32", "f16x3", "f16x3g", "f16"])
 @pytest.mark.parametrize("S,T,B,H,csr", [(34, 24, 256, 102, False), (7, 12, 32, 21, False), (5, 3, 17, 9, False),
                                          (20, 4, 6, 200, False), (100, 3, 4, 60, True), (64, 2, 3, 127, False)])
 def test_finish_kernel_equals_the_separate_reduce_adam_and_prepare_passes(S, T, B, H, csr, math):
@@ -1075,7 +1078,7 @@ def test_finish_kernel_equals_the_separate_reduce_adam_and_prepare_passes(S, T, 
     X = torch.rand(B, T, S, 13, generator=g).to(dev)
     L = torch.rand(B, T, H, generator=g).to(dev)
     p0 = orc.init_params(S, 13, H, seed=S + H)
-    mode = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3, "f16": _lib.MATH_F16}[math]
+    mode = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3, "f16": _lib.MATH_F16, "f16x3g": _lib.MATH_F16X3G}[math]
     hyper = dict(step=3, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8)
 
     def fresh():
@@ -1169,3 +1172,31 @@ def test_backward_told_the_loss_statistics_are_in_the_stash_when_they_are_not_is
     assert abs(float(loss) - float(fx["loss"])) <= 1e-5
     for a, b in zip(gs, good):
         assert rel_to_max(a.cpu(), b.cpu()) <= 1e-5
+
+
+def test_f16x3g_is_f16x3_below_4096_rows_and_within_tolerance_above():
+    """WGNN_MATH_F16X3G (bench.py's default): below B*T = 4096 rows it is WGNN_MATH_F16X3 bit for bit; from there on the
+    forward is still identical (Y bitwise) and the MSE-driven gradients stay inside G_TOL of the fp64 oracle with room to
+    spare (observed at B*T = 6144: 6e-6 of max, f16x3: 1.3e-6; tools/grad_error_probe.py)."""
+    from oracle import windgnn_oracle as orc
+    dev = _dev()
+    S, T, H = 34, 24, 102
+    p = orc.init_params(S, 13, H, seed=3)
+    A = torch.from_numpy(load_fixture("f3b_s34_t24_b4_rand")["A"])
+    for B, same in ((170, True), (256, False)):          # 4080 and 6144 rows
+        g = torch.Generator().manual_seed(B)
+        X = torch.rand(B, T, S, 13, generator=g)
+        L = torch.rand(B, T, H, generator=g)
+        res = {}
+        for math in ("f16x3", "f16x3g"):
+            res[math] = _run_step(_model_from(p, S, H, math), A.to(dev), X.to(dev), L.to(dev))
+        assert torch.equal(res["f16x3"][0], res["f16x3g"][0])                      # the forward is the same code
+        if same:
+            for k in PARAM_KEYS:
+                assert torch.equal(res["f16x3"][2][k], res["f16x3g"][2][k]), k
+            continue
+        assert any(not torch.equal(res["f16x3"][2][k], res["f16x3g"][2][k]) for k in PARAM_KEYS)   # the two-pass GEMMs ran
+        Yo, loss_o, go = orc.train_step(A.double(), X.double(), L.double(), {k: v.double() for k, v in p.items()})
+        for k in PARAM_KEYS:
+            assert rel_to_max(res["f16x3g"][2][k], go[k]) <= 2e-5, k                # 5x inside G_TOL
+            assert rel_to_max(res["f16x3"][2][k], go[k]) <= 5e-6, k

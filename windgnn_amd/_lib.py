@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libwindgnn_hip.so")
 MATH_F32 = 0
 MATH_F16X3 = 1
 MATH_F16 = 2
+MATH_F16X3G = 3       # f16x3 whose backward gate gradients travel as one fp16 plane from B*T >= 4096 (include/windgnn.h)
 ADJ_DENSE = 0
 ADJ_CSR = 1
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2   # wgnn_io: element type of X, Y and the labels

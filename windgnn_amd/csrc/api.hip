@@ -27,6 +27,7 @@ struct Layout {
   bool x3, gen_gcn, gen_gru, g32, g32tn;
   int hq;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
+  bool dgi1;                                     // f16x3 at large B*T: dGI / dGHn are ONE fp16 plane, their three GEMMs run two passes
   bool small, rec32;                             // exact fp32: one-window-per-workgroup recurrences / the register-resident MFMA ones
   size_t st_hprev;                               // exact fp32, large B*T: [Hprev | 1 | 0..] rows written by the forward recurrence
   bool dghn;                                     // only the n third of dGH is stored (dGHn): fast f16x3 recurrence; rec32 at large B*T
@@ -106,6 +107,10 @@ Layout make_layout(const wgnn_dims* d) {
   L.st_hprev = o; o += al(L.g32tn ? L.BT * (size_t)L.hq : 0);     // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
   L.stash_floats = o;
   L.dghn = (x3 && !L.gen_gru) || (L.rec32 && L.g32tn);
+  // WGNN_MATH_F16X3G, from B*T = 4096 rows: dGI / dGHn travel as ONE fp16 plane (relative rounding 2^-12, independent per
+  // element); it averages out in everything they feed -- the weight gradients sum B*T rows, the conv gradients B*T*S -- and
+  // the lo plane is not written, staged or multiplied (error model and measured errors)
+  L.dgi1 = d->math == WGNN_MATH_F16X3G && !L.gen_gru && L.BT >= 4096;
   L.hn = x3 ? grux_hn(d->H) : gru_hn(d->H);
   L.msplit = x3 ? grux_msplit(d->H) : gru_msplit(d->H);
   // GEMM rows of the dW_hh product: [dGI_r | dGI_z | pad to msplit | dGHn]
@@ -187,7 +192,7 @@ void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float
   if (which & 2) {
     a.conv_partial = ws + L.ws_gcnpart;
     a.conv_rows = L.gen_gcn ? gcn_csr_bwd_rows()
-                            : (L.x3 ? gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3) : gcn32_bwd_grid((int)L.BT));
+                            : (L.x3 ? gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G) : gcn32_bwd_grid((int)L.BT));
   }
 }
 
@@ -196,7 +201,8 @@ int check_dims(const wgnn_dims* d) {
   if (d->B < 1 || d->T < 1 || d->S < 1 || d->H < 1) return WGNN_ERR_SHAPE;
   if (d->F != 13) return WGNN_ERR_SHAPE;            // the reference hard-codes 13 (step6:16)
   if ((int64_t)d->B * d->T > (1 << 30)) return WGNN_ERR_SHAPE;
-  if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3 && d->math != WGNN_MATH_F16) return WGNN_ERR_DTYPE;
+  if (d->math != WGNN_MATH_F32 && d->math != WGNN_MATH_F16X3 && d->math != WGNN_MATH_F16 && d->math != WGNN_MATH_F16X3G)
+    return WGNN_ERR_DTYPE;
   if (d->io != WGNN_IO_F32 && d->io != WGNN_IO_F16 && d->io != WGNN_IO_BF16) return WGNN_ERR_DTYPE;
   // 16-bit X / Y / labels: only the fp16-plane kernel family with the dense LDS-resident GCN and the register-resident GRU
   if (d->io != WGNN_IO_F32 &&
@@ -275,7 +281,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   float* g = sf ? sf + L.st_g : ws + L.ws_g;
   float* gates = sf ? sf + L.st_gates : nullptr;
   const bool x3 = L.x3;                              // fp16-plane kernels
-  const bool full = d->math == WGNN_MATH_F16X3;      // three-pass split products (false: one fp16 pass)
+  const bool full = d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G;   // three-pass split products (false: one fp16 pass)
   // the staged image of [W_ih | b_ih]: the caller's (wgnn_prepare_weights / wgnn_finish keep it current) or rebuilt here
   const bool kept = p->prepared != nullptr && L.prep_kind != 0;
   float* img_f = kept ? (float*)p->prepared + L.prep_f : ws + L.ws_planes_f;
@@ -500,7 +506,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
   float* img_b = kept ? (float*)p->prepared + L.prep_b : ws + L.ws_planes_b;     // staged image of W_ih^T
   float* scales = ws + L.ws_scales;          // [0] = 2^k, [1] = 2^-k (f16x3 range scaling), [2] = dY coefficient; partials from 64
   const bool x3 = L.x3;
-  const bool full = d->math == WGNN_MATH_F16X3;
+  const bool full = d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G;
   auto reduce_now = [&](int parts) {                 // without WGNN_BWD_DEFER: the reduce-only form of the finish launch
     FinishArgs fa = {};
     fill_reduce(L, d, g, ws, parts, fa);
@@ -525,6 +531,8 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     const _Float16* gh = (const _Float16*)gact;
     const _Float16* yph = (const _Float16*)(sf + L.st_yp);
     const size_t PG = L.BT * L.Gp;
+    const _Float16* dGIlo = L.dgi1 ? nullptr : dGIh + PG;                    // nullptr: single-plane A operand, two passes
+    const _Float16* dGHnlo = L.dgi1 ? nullptr : dGHh + L.BT * (size_t)L.hn;
     if (do_rec) {
       if (fused_loss && stats_ready)   // the forward recurrence already reduced (Y - labels): the BPTT kernel finalises
         rc = WGNN_OK;
@@ -543,7 +551,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
         rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Yv, fused_loss ? nullptr : dY, fused_loss ? labelsv : nullptr,
                              d->io, gates, scales, dGIh, dGHh, (int)L.Gp, full,
                              fused_loss && stats_ready ? sf + L.st_stats : nullptr, (int64_t)L.BT * L.H, grad_scale, loss,
-                             scales, status, st);
+                             scales, status, L.dgi1 ? 0 : 1, st);
       }
       if (rc != WGNN_OK) return rc;
     }
@@ -552,16 +560,16 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       // Register-resident recurrence: dGH = [dGI_r | dGI_z | dGHn], the A operand takes GEMM rows < msplit from the dGI
       // planes and rows >= msplit from the dGHn planes; the reduce kernel maps the GEMM rows back to W_hh's rows.
       if (L.dghn) {
-        rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
-                             L.sk_hh, part_hh, L.m_hh, (int)L.H + 1, full, dGHh, dGHh + L.BT * (size_t)L.hn, L.hn, L.msplit, st);
+        rc = launch_pgemm_tn(dGIh, dGIlo, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
+                             L.sk_hh, part_hh, L.m_hh, (int)L.H + 1, full, dGHh, dGHnlo, L.hn, L.msplit, st);
       } else {
         rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
                              L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, full, nullptr, nullptr, 0, 0, st);
       }
       if (rc != WGNN_OK) return rc;
       // dW_ih | db_ih = dGI^T [g | 1]
-      rc = launch_pgemm_tn(dGIh, dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT, L.sk_ih, part_ih,
-                           (int)L.G3, (int)L.I + 1, full, nullptr, nullptr, 0, 0, st);
+      rc = launch_pgemm_tn(dGIh, L.gen_gru ? dGIh + PG : dGIlo, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT,
+                           L.sk_ih, part_ih, (int)L.G3, (int)L.I + 1, full, nullptr, nullptr, 0, 0, st);
       if (rc != WGNN_OK) return rc;
       if (!defer) rc = reduce_now(4);
       if (rc != WGNN_OK) return rc;
@@ -572,7 +580,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, img_b, L.np_i, (int)L.Gp, status, st);
       if (rc != WGNN_OK) return rc;
     }
-    rc = launch_pgemm_nt(dGIh, dGIh + PG, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.I,
+    rc = launch_pgemm_nt(dGIh, L.gen_gru ? dGIh + PG : dGIlo, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.I,
                          (int)L.I, nullptr, full, nullptr, st);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gcn) {

@@ -129,7 +129,8 @@ int grux_msplit(int H);   // 8*ceil(2H/8): first GEMM row of the dGHn block in t
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
                     const float* gates,
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, const float* stat_part,
-                    int64_t n_loss, float grad_scale, float* loss, float* scales_out, unsigned* status, hipStream_t st);
+                    int64_t n_loss, float grad_scale, float* loss, float* scales_out, unsigned* status,
+                    int write_lo /*0: dGI / dGHn as one fp16 plane (x3 only)*/, hipStream_t st);
 #define WGNN_STATS_TAG 20261004.0f   // float word behind the MSE partial pairs: "wgnn_fwd_loss wrote these"
 
 int launch_gcn_partial_reduce(const float* partial, int nblk, float* dW1, float* db1, float* dW2, float* db2,

@@ -393,7 +393,10 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
                                                             _Float16* __restrict__ dGN_lo,
                                                             const float* __restrict__ stat_part, int nstat, float inv_n,
                                                             float coef_in, float* __restrict__ loss_out,
-                                                            float* __restrict__ scales_out, unsigned* status) {
+                                                            float* __restrict__ scales_out, unsigned* status,
+                                                            int write_lo) {
+  // write_lo == 0 (X3, large B*T): dGI / dGHn leave the chip as ONE fp16 plane (the lo halves stay in LDS, where the
+  // recurrence's own product dgh W_hh uses them): the three GEMMs that consume them run two passes
   constexpr int DS = 32 * KSB + 8;
   // stat_part != null (wgnn_bwd_mse_part(.. | 8) after wgnn_fwd_loss): the loss, the power-of-two range scale and the dY
   // coefficient are finalised HERE from the forward recurrence's nstat partial pairs (sum | max), by every workgroup for
@@ -503,7 +506,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
       c_step[i] = 0;
       if (q < n_i) {
         const int plane = q / (MB * cpr), rem = q % (MB * cpr), m = rem / cpr, ch = rem % cpr;
-        if (b0 + m < B && (X3 || plane == 0)) {
+        if (b0 + m < B && ((X3 && write_lo) || plane == 0)) {
           c_lds[i] = (2 + plane) * MB * DS + m * DS + 8 * ch;
           c_dst[i] = (plane ? dGI_lo : dGI_hi) + ((size_t)(b0 + m) * T) * ldd + 8 * ch;
           c_step[i] = ldd;
@@ -511,7 +514,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
       } else if (q - n_i < n_n) {
         q -= n_i;
         const int plane = q / (MB * cpn), rem = q % (MB * cpn), m = rem / cpn, ch = rem % cpn;
-        if (b0 + m < B && (X3 || plane == 0)) {
+        if (b0 + m < B && ((X3 && write_lo) || plane == 0)) {
           c_lds[i] = plane * MB * DS + m * DS + MS + 8 * ch;
           c_dst[i] = (plane ? dGN_lo : dGN_hi) + ((size_t)(b0 + m) * T) * HN + 8 * ch;
           c_step[i] = HN;
@@ -725,7 +728,8 @@ int grux_msplit(int H) { return 8 * cdiv_i(2 * H, 8); }
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
                     const float* gates,
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, const float* stat_part,
-                    int64_t n_loss, float grad_scale, float* loss, float* scales_out, unsigned* status, hipStream_t st) {
+                    int64_t n_loss, float grad_scale, float* loss, float* scales_out, unsigned* status, int write_lo,
+                    hipStream_t st) {
   // stat_part != null: loss and scales are finalised inside the kernel (once a separate one-block launch)
   const int nstat = grux_blocks(B);
   const float inv_n = stat_part ? 1.0f / (float)n_loss : 0.f, coef_in = stat_part ? 2.0f * grad_scale / (float)n_loss : 0.f;
@@ -742,10 +746,10 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
 #define BLAUNCH(K, X3V, IOV, NAME, BYTES)                                                                         \
   PROF_LAUNCH(NAME, fl, BYTES, st,                                                                                \
               hipLaunchKernelGGL((grux_bwd_kernel<K, X3V, IOV>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, io, \
-                                 gates, scales, ih, il, ldd, nh, nl, stat_part, nstat, inv_n, coef_in, loss, scales_out, status))
+                                 gates, scales, ih, il, ldd, nh, nl, stat_part, nstat, inv_n, coef_in, loss, scales_out, status, write_lo))
 #define BCASE(K)                                                                                                  \
-  if (x3 && !io) BLAUNCH(K, true, false, "grux_bwd_kernel<" #K ">", by);                                          \
-  else if (x3) BLAUNCH(K, true, true, "grux_bwd_kernel<" #K ">", by);                                             \
+  if (x3 && !io) BLAUNCH(K, true, false, "grux_bwd_kernel<" #K ">", write_lo ? by : by * 0.875);                  \
+  else if (x3) BLAUNCH(K, true, true, "grux_bwd_kernel<" #K ">", write_lo ? by : by * 0.875);                                             \
   else if (!io) BLAUNCH(K, false, false, "grux_bwd_kernel<" #K ",f16>", by * 0.75);                               \
   else BLAUNCH(K, false, true, "grux_bwd_kernel<" #K ",f16>", by * 0.75)
   switch (ksb) {

@@ -41,7 +41,9 @@ __device__ __forceinline__ f32x4 mfma_q(h8 a, h8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int T, bool X3>
+// ALO (with X3): the A operand has a lo plane (three passes lo*hi + hi*lo + hi*hi); false: A is a single fp16 plane and
+// the product is hi*lo + hi*hi (two passes, no A-lo staging) -- the backward's dGI at large B*T, see DESIGN.md section 3.
+template <int T, bool X3, bool ALO>
 __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16* __restrict__ Ahi,
                                                                 const _Float16* __restrict__ Alo, int lda, int M,
                                                                 int Kp, const _Float16* __restrict__ Bpl, int Np,
@@ -61,9 +63,10 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
   }
   constexpr int BM = NT_BM, BNW = 16 * T, BN = 2 * BNW;
   constexpr int A_PL = BM * 64, B_PL = BN * 64, STAGE = 2 * A_PL + 2 * B_PL;
-  constexpr int PL = X3 ? 2 : 1;                                   // planes moved: hi (+ lo)
+  constexpr int PL = X3 ? 2 : 1;                                   // B planes moved: hi (+ lo)
+  constexpr int PLA = (X3 && ALO) ? 2 : 1;                         // A planes moved
   constexpr int AP = BM / 16, BP = BN / 16;                        // 1 KB pieces per plane
-  constexpr int NPIECE = PL * (AP + BP), NIT = (NPIECE + NT_WAVES - 1) / NT_WAVES;
+  constexpr int NPIECE = PLA * AP + PL * BP, NIT = (NPIECE + NT_WAVES - 1) / NT_WAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: LDS-DMA bases go to M0
@@ -103,14 +106,14 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     on[it] = p < NPIECE;                                            // wave-uniform
     const int pp = on[it] ? p : 0;
     const int chunk = 8 * (ppos ^ swz16(prow));
-    if (pp < PL * AP) {
+    if (pp < PLA * AP) {
       const int plane = pp / AP, blk = pp % AP;
       const int gr = min(m0 + 16 * blk + prow, M - 1);            // rows past M are computed but never stored
       src[it] = (plane ? Alo : Ahi) + (a_sm ? (size_t)gr * 32 + chunk : (size_t)gr * lda + chunk);
       dst[it] = plane * A_PL + blk * 1024;
       kadv[it] = a_sm ? M * 32 : 32;
     } else {
-      const int q = pp - PL * AP;
+      const int q = pp - PLA * AP;
       const int plane = q / BP, blk = q % BP;
       src[it] = Bpl + (size_t)plane * bplane + (size_t)(n0 + 16 * blk + prow) * 32 + chunk;
       dst[it] = 2 * A_PL + plane * B_PL + blk * 1024;
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     ah[1] = *(const h8*)(Ah + a_off1);
     al[0] = ah[0];
     al[1] = ah[1];
-    if (X3) {
+    if (X3 && ALO) {
       al[0] = *(const h8*)(Al + a_off0);
       al[1] = *(const h8*)(Al + a_off1);
     }
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
         const h8 bl = *(const h8*)(Bl + j * 1024);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          acc[i][j] = mfma_q(al[i], bh, acc[i][j]);
+          if (ALO) acc[i][j] = mfma_q(al[i], bh, acc[i][j]);
           acc[i][j] = mfma_q(ah[i], bl, acc[i][j]);
         }
       }
@@ -207,7 +210,8 @@ __device__ __forceinline__ int tn_g(int stride32, int r) {   // stride32 = row b
 // A2 (template flag): the A operand's columns m >= msplit come from a second pair of planes, column m - msplit of
 // A2hi / A2lo (row stride lda2); msplit is a multiple of 8 so no 16-byte chunk straddles the two sources.  Used for
 // dW_hh = [dGI_r | dGI_z | dGH_n]^T Hprev: the BPTT kernel stores the n third of dGH only (its r and z thirds equal dGI's).
-template <int T, bool X3, bool A2>
+// ALO (with X3): as in pgemm_nt_kernel -- false: the A operand (dGI [+ dGHn]) is a single fp16 plane, two passes.
+template <int T, bool X3, bool A2, bool ALO>
 __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16* __restrict__ Ahi,
                                                                 const _Float16* __restrict__ Alo, int lda,
                                                                 const _Float16* __restrict__ Bhi,
@@ -220,9 +224,10 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
   constexpr int BM = TN_BM, BN = 32 * T;
   constexpr int ARB = BM * 2, BRB = BN * 2;                         // row bytes
   constexpr int A_PL = 32 * ARB, B_PL = 32 * BRB, STAGE = 2 * A_PL + 2 * B_PL;
-  constexpr int PL = X3 ? 2 : 1;                                   // planes moved: hi (+ lo)
+  constexpr int PL = X3 ? 2 : 1;                                   // B planes moved: hi (+ lo)
+  constexpr int PLA = (X3 && ALO) ? 2 : 1;                         // A planes moved
   constexpr int AP = A_PL / 1024, BP = B_PL / 1024;                // 1 KB pieces per plane
-  constexpr int NPIECE = PL * (AP + BP), NIT = (NPIECE + TN_WAVES - 1) / TN_WAVES;
+  constexpr int NPIECE = PLA * AP + PL * BP, NIT = (NPIECE + TN_WAVES - 1) / TN_WAVES;
   constexpr int ACH = ARB / 16, BCH = BRB / 16;                    // 16-byte chunks per row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -250,7 +255,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
     const int p = wave + TN_WAVES * it;
     on[it] = p < NPIECE;                                            // wave-uniform
     const int pp = on[it] ? p : 0;
-    isb[it] = pp >= PL * AP;
+    isb[it] = pp >= PLA * AP;
     if (!isb[it]) {
       const int plane = pp / AP, q = 64 * (pp % AP) + lane;
       const int row = q / ACH, pos = q % ACH;
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
       }
       dst[it] = plane * A_PL + (pp % AP) * 1024;
     } else {
-      const int q2 = pp - PL * AP;
+      const int q2 = pp - PLA * AP;
       const int plane = q2 / BP, q = 64 * (q2 % BP) + lane;
       const int row = q / BCH, pos = q % BCH;
       const int col = n0 + 8 * (pos ^ (2 * tn_g(BRB / 32, row)));
@@ -317,7 +322,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
     for (int i = 0; i < 5; ++i) {
       ah[i] = trread(cur + a_off[i], ARB);
       al[i] = ah[i];
-      if (X3) al[i] = trread(cur + A_PL + a_off[i], ARB);
+      if (X3 && ALO) al[i] = trread(cur + A_PL + a_off[i], ARB);
     }
 #pragma unroll
     for (int j = 0; j < T; ++j) {
@@ -326,7 +331,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
         const h8 bl = trread(cur + B_PL + b_off[j], BRB);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-          acc[i][j] = mfma_q(al[i], bh, acc[i][j]);
+          if (ALO) acc[i][j] = mfma_q(al[i], bh, acc[i][j]);
           acc[i][j] = mfma_q(ah[i], bl, acc[i][j]);
         }
       }
@@ -346,7 +351,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
       const u32x4 zero = {0u, 0u, 0u, 0u};
       for (int c = tid; c < (32 - rows) * ACH; c += 64 * TN_WAVES) {
         *(u32x4*)(cur + rows * ARB + 16 * c) = zero;
-        if (X3) *(u32x4*)(cur + A_PL + rows * ARB + 16 * c) = zero;
+        if (X3 && ALO) *(u32x4*)(cur + A_PL + rows * ARB + 16 * c) = zero;
       }
       __syncthreads();
     }
@@ -433,13 +438,16 @@ int pgemm_nt_np(int N) { return cdiv_i(N, 32) * 32 + 448 - 32; }
 template <int T>
 static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
                        int ldc, int N, const float* s_out, bool x3, int nsl, float* kpart, hipStream_t st) {
+  const bool alo = Alo != nullptr;                 // x3 with a single-plane A operand: two passes
   const int nm = cdiv_i(M, NT_BM);
   const int grid = (nm >= 8 ? cdiv_i(nm, 8) * 8 : nm) * nsl;
   const size_t smem = 2 * (size_t)(2 * NT_BM + 2 * 32 * T) * 64;
-  static std::atomic<unsigned long long> done{0}, done16{0};
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
-  static const std::string name = "pgemm_nt_kernel<" + std::to_string(T) + ">", name16 = "pgemm_nt_kernel<" + std::to_string(T) + ",f16>";
+  static std::atomic<unsigned long long> done{0}, done16{0}, done2{0};
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false>, smem, done2) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
+  static const std::string name = "pgemm_nt_kernel<" + std::to_string(T) + ">", name16 = "pgemm_nt_kernel<" + std::to_string(T) + ",f16>",
+                           name2 = "pgemm_nt_kernel<" + std::to_string(T) + ",x2>";
   // Long contractions (the 4096-station projections: K = 53 248) run as 2048-wide K chunks: an fp32 accumulator
   // chain of at most 64 MFMA steps per chunk keeps the summation error at fp32-GEMM level.  With split-K scratch
   // the chunks are blocks of ONE launch (partials summed in fixed order); without, one launch per chunk adds onto C.
@@ -454,15 +462,21 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
     const size_t cstride = split ? (size_t)M * ldc : 0;
     const double kk = split ? Kp : (Kp - c * kc_len < kc_len ? Kp - c * kc_len : kc_len);
     const double fl = 2.0 * M * (double)N * kk;
-    const double by = (x3 ? 4.0 : 2.0) * ((double)M * kk + (double)Np * kk) + 4.0 * (double)M * N * (split ? nchunks : (c > 0 ? 2 : 1));
-    if (x3)
+    const double by = (x3 && alo ? 4.0 : 2.0) * (double)M * kk + (x3 ? 4.0 : 2.0) * (double)Np * kk +
+                      4.0 * (double)M * N * (split ? nchunks : (c > 0 ? 2 : 1));
+    if (x3 && alo)
       PROF_LAUNCH(name.c_str(), fl, by, st,
-                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
+                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0, a_sm));
+    else if (x3)
+      PROF_LAUNCH(name2.c_str(), fl, by, st,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                                     (const _Float16*)Ahi, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
                                      nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0, a_sm));
     else
       PROF_LAUNCH(name16.c_str(), fl, by, st,
-                  hipLaunchKernelGGL((pgemm_nt_kernel<T, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, false, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
                                      nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0, a_sm));
     WGNN_CHECK_LAUNCH();
@@ -512,32 +526,40 @@ static int launch_tn_t(const void* Ahi, const void* Alo, int lda, const void* Bh
   const int nMb = cdiv_i(Mout, TN_BM);
   const int kchunk = cdiv_i(cdiv_i(K, splitk), 32) * 32;
   const size_t smem = 2 * (size_t)(2 * 32 * 2 * (TN_BM + 32 * T));
-  static std::atomic<unsigned long long> done{0}, done16{0}, done2{0}, done216{0};
-  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, true, false>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, false, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
+  const bool alo = Alo != nullptr;                 // x3 with a single-plane A operand (Alo == nullptr): two passes
   const double fl = 2.0 * Mout * (double)Nout * K;
-  const double by = (x3 ? 4.0 : 2.0) * ((double)K * Mout + (double)K * Nout) + 4.0 * (double)splitk * Mout * Nout;
+  const double by = (x3 && alo ? 4.0 : 2.0) * (double)K * Mout + (x3 ? 4.0 : 2.0) * (double)K * Nout +
+                    4.0 * (double)splitk * Mout * Nout;
   static const std::string name = "pgemm_tn_kernel<" + std::to_string(T) + ">",
-                           name16 = "pgemm_tn_kernel<" + std::to_string(T) + ",f16>";
+                           name16 = "pgemm_tn_kernel<" + std::to_string(T) + ",f16>",
+                           name2 = "pgemm_tn_kernel<" + std::to_string(T) + ",x2>";
   const dim3 grid(splitk, nMb * nNb), block(64 * TN_WAVES);
+  if (!alo) { Alo = Ahi; A2lo = A2hi; }            // never read
 #define TN_ARGS (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi, (const _Float16*)Blo, ldb, shift_T, K, \
                 kchunk, partial, Mout, Nout, nNb, (const _Float16*)A2hi, (const _Float16*)A2lo, lda2, msplit
+#define TN_GO(NAME, X3V, A2V, ALOV)                                                                                  \
+  do {                                                                                                               \
+    static std::atomic<unsigned long long> done_{0};                                                                 \
+    if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, X3V, A2V, ALOV>, smem, done_) != WGNN_OK) return WGNN_ERR_HIP; \
+    PROF_LAUNCH(NAME.c_str(), fl, by, st,                                                                            \
+                hipLaunchKernelGGL((pgemm_tn_kernel<T, X3V, A2V, ALOV>), grid, block, smem, st, TN_ARGS));           \
+  } while (0)
   if (A2hi) {
     if constexpr (T <= 4) {     // only the narrow dW_hh product has a two-source A operand
-      if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, true, true>, smem, done2) != WGNN_OK) return WGNN_ERR_HIP;
-      if (ensure_dyn_smem((const void*)pgemm_tn_kernel<T, false, true>, smem, done216) != WGNN_OK) return WGNN_ERR_HIP;
-      if (x3)
-        PROF_LAUNCH(name.c_str(), fl, by, st, hipLaunchKernelGGL((pgemm_tn_kernel<T, true, true>), grid, block, smem, st, TN_ARGS));
-      else
-        PROF_LAUNCH(name16.c_str(), fl, by, st, hipLaunchKernelGGL((pgemm_tn_kernel<T, false, true>), grid, block, smem, st, TN_ARGS));
+      if (x3 && alo) TN_GO(name, true, true, true);
+      else if (x3) TN_GO(name2, true, true, false);
+      else TN_GO(name16, false, true, true);
     } else {
       return WGNN_ERR_UNSUPPORTED;
     }
+  } else if (x3 && alo) {
+    TN_GO(name, true, false, true);
   } else if (x3) {
-    PROF_LAUNCH(name.c_str(), fl, by, st, hipLaunchKernelGGL((pgemm_tn_kernel<T, true, false>), grid, block, smem, st, TN_ARGS));
+    TN_GO(name2, true, false, false);
   } else {
-    PROF_LAUNCH(name16.c_str(), fl, by, st, hipLaunchKernelGGL((pgemm_tn_kernel<T, false, false>), grid, block, smem, st, TN_ARGS));
+    TN_GO(name16, false, false, true);
   }
+#undef TN_GO
 #undef TN_ARGS
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;

@@ -63,7 +63,7 @@ class GCN_GRU(nn.Module):
         self.conv1 = GraphConvLayer(input_dim, hidden_dim)
         self.conv2 = GraphConvLayer(hidden_dim, output_dim)
         self.gru = _GRUParams(gru_input, gru_hidden_dim)
-        self.math = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3, "f16": _lib.MATH_F16}[math]
+        self.math = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3, "f16": _lib.MATH_F16, "f16x3g": _lib.MATH_F16X3G}[math]
 
     def hot_path_parameters(self):
         return (self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
