@@ -169,7 +169,7 @@ def cpu_baseline(budget_s=10.0, Bc=1024, faithful_budget_s=8.0):
 
 
 def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
-    """One more configuration timed on the same box: `nsteps` full training steps (TrainStep.step) after 3 warm-up steps,
+    """One more configuration timed on the same box: `nsteps` full training steps (TrainStep.step) after 10 warm-up steps,
     inputs resident; with `forward` also the forward-only time against its own algorithmic bytes (X + Y in the I/O type)."""
     from windgnn_amd import GCN_GRU
     from windgnn_amd.functional import gcn_gru_forward_raw
@@ -178,7 +178,7 @@ def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
     m = GCN_GRU(F, F, F, S * F, H, math=math).to(dev)
     tr = TrainStep(m)
     X, L = make_inputs(B, 0, dev, S, H, io)
-    for _ in range(3):
+    for _ in range(10):                                  # first launches of this mode's kernels + clocks
         tr.step(A, X, L)
     torch.cuda.synchronize()
     s0 = time.perf_counter()

@@ -72,12 +72,13 @@ typedef enum wgnn_math {
   WGNN_MATH_F16X3 = 1, /* split-fp16 (hi+lo) MFMA, 3 products, fp32 accumulate: fp32-grade error */
   WGNN_MATH_F16 = 2,   /* plain fp16 operands, one MFMA pass, fp32 accumulate: ~1e-3 error (16-bit config) */
   WGNN_MATH_F16X3G = 3 /* F16X3, except that from B*T >= 4096 rows the backward's gate gradients (dGI, dGH_n) leave the BPTT
-                          kernel as ONE fp16 plane, so the three GEMMs they feed (dW_ih, dW_hh, dg) run two MFMA passes
-                          instead of three.  Forward and recurrences are F16X3's (Y identical).  Gradients: each dGI element
-                          carries an independent relative rounding of 2^-12, which averages out over the B*T rows a weight
-                          gradient sums -- observed 6e-6 of the tensor's max against the fp64 oracle at B*T = 6144 with the
-                          MSE loss (F16X3: 1e-6), and at worst ~4e-4 when dY is pure zero-mean noise (a gradient that is
-                          itself a fully cancelling sum).  Below 4096 rows it IS F16X3, bit for bit. */
+                          kernel as ONE fp16 plane and the three GEMMs they feed run fewer MFMA passes: dW_hh and dg two
+                          (hi x (hi + lo)), dW_ih one (hi x hi).  Forward, recurrences and the GCN backward are F16X3's
+                          (Y identical).  Gradients: every dropped lo half is a relative rounding of 2^-12, independent
+                          per element, that averages out over the B*T rows a weight gradient sums -- observed <= 9e-6 of
+                          the tensor's max against the fp64 oracle at B*T = 6144 with the MSE loss (F16X3: 1.3e-6), and
+                          at worst ~4e-4 when dY is pure zero-mean noise (a gradient that is itself a fully cancelling
+                          sum).  Below 4096 rows it IS F16X3, bit for bit. */
 } wgnn_math;
 
 /* Adjacency argument `A` of wgnn_fwd / wgnn_bwd:

@@ -568,8 +568,12 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       }
       if (rc != WGNN_OK) return rc;
       // dW_ih | db_ih = dGI^T [g | 1]
-      rc = launch_pgemm_tn(dGIh, L.gen_gru ? dGIh + PG : dGIlo, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT,
-                           L.sk_ih, part_ih, (int)L.G3, (int)L.I + 1, full, nullptr, nullptr, 0, 0, st);
+      // (single-plane dGI: ONE pass, hi(dGI) x hi(g) -- the rounding of g, too, is independent per element and averages
+      // out over the B*T rows this product sums: measured 8.8e-6 of max at B*T = 6144 against 5.9e-6 with g's lo plane.
+      // The same was measured for dW_hh (7e-5: h rows are correlated) and dg (2.8e-4 on the conv gradients: the rounding
+      // of W_ih is the same for every row and does not average) and NOT adopted: they keep hi x (hi + lo).)
+      rc = launch_pgemm_tn(dGIh, L.dgi1 ? dGIh : dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT,
+                           L.sk_ih, part_ih, (int)L.G3, (int)L.I + 1, full && !L.dgi1, nullptr, nullptr, 0, 0, st);
       if (rc != WGNN_OK) return rc;
       if (!defer) rc = reduce_now(4);
       if (rc != WGNN_OK) return rc;

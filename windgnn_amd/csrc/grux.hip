@@ -741,17 +741,18 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
   if (ldd % 8 != 0 || ldd < 3 * H || ldd > 32 * ksb) return WGNN_ERR_SHAPE;
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H,
-               by = bt * ((io ? 2.0 + 4.0 : 4.0 + 4.0) * H + 4.0 * (3 * H + H)) + 4.0 * grux_gates_floats(B, T, H, io);
+               by = bt * ((io ? 2.0 + 4.0 : 4.0 + 4.0) * H + (x3 && write_lo ? 4.0 : 2.0) * (3 * H + H)) +
+                    4.0 * grux_gates_floats(B, T, H, io);      // Y + labels in, dGI + dGHn planes out (hi [+ lo]), gate stash in
   const dim3 grid(cdiv_i(B, MB));
 #define BLAUNCH(K, X3V, IOV, NAME, BYTES)                                                                         \
   PROF_LAUNCH(NAME, fl, BYTES, st,                                                                                \
               hipLaunchKernelGGL((grux_bwd_kernel<K, X3V, IOV>), grid, dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY, labels, io, \
                                  gates, scales, ih, il, ldd, nh, nl, stat_part, nstat, inv_n, coef_in, loss, scales_out, status, write_lo))
 #define BCASE(K)                                                                                                  \
-  if (x3 && !io) BLAUNCH(K, true, false, "grux_bwd_kernel<" #K ">", write_lo ? by : by * 0.875);                  \
-  else if (x3) BLAUNCH(K, true, true, "grux_bwd_kernel<" #K ">", write_lo ? by : by * 0.875);                                             \
-  else if (!io) BLAUNCH(K, false, false, "grux_bwd_kernel<" #K ",f16>", by * 0.75);                               \
-  else BLAUNCH(K, false, true, "grux_bwd_kernel<" #K ",f16>", by * 0.75)
+  if (x3 && !io) BLAUNCH(K, true, false, "grux_bwd_kernel<" #K ">", by);                                          \
+  else if (x3) BLAUNCH(K, true, true, "grux_bwd_kernel<" #K ">", by);                                             \
+  else if (!io) BLAUNCH(K, false, false, "grux_bwd_kernel<" #K ",f16>", by);                                      \
+  else BLAUNCH(K, false, true, "grux_bwd_kernel<" #K ",f16>", by)
   switch (ksb) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;
