@@ -6,8 +6,8 @@ tag=${1:-rX}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-python bench.py --steps 20 --warmup 20 > $out/${tag}_bench_driver_shape.json 2> $out/bench.err
-python bench.py > $out/${tag}_bench.json 2>> $out/bench.err
+python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_driver_shape.json 2> $out/bench.err      # the driver's own command line
+python bench.py --no-cpu-baseline > $out/${tag}_bench.json 2>> $out/bench.err                        # 200 steps
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline --no-traffic --no-secondary > $out/bench_under_rocprof.json 2> $out/stats.err
 cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/${tag}_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmcF -- python3 bench.py --traffic-child --steps 5 --warmup 1 > /dev/null 2> $out/pmcF.err
