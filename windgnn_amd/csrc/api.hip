@@ -192,7 +192,7 @@ void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float
   if (which & 2) {
     a.conv_partial = ws + L.ws_gcnpart;
     a.conv_rows = L.gen_gcn ? gcn_csr_bwd_rows()
-                            : (L.x3 ? gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G) : gcn32_bwd_grid((int)L.BT));
+                            : (L.x3 ? gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G) : gcn32_bwd_grid((int)L.BT, d->S));
   }
 }
 

@@ -227,7 +227,7 @@ int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY
 // ---- finish.hip: reduction of the deferred partial sums + Adam + the prepared W_ih images, one launch
 constexpr int TN_BM = 320, TN_WAVES = 8;     // pgemm_tn_kernel's workgroup tile rows / waves (its partial layout)
 void pgemm_tn_geom(int Mgemm, int Nout, int* T, int* nNb, int* ntiles);
-int gcn32_bwd_grid(int ntiles);              // partial rows launch_gcn32_bwd writes
+int gcn32_bwd_grid(int ntiles, int S);       // partial rows launch_gcn32_bwd writes
 int gcn_csr_bwd_rows();                      // partial rows launch_gcn2_csr_bwd writes
 struct FinSeg {                // one split-K weight-gradient product: C[Mout][ncols] and its bias column Nout - 1
   const float* partial;

@@ -202,9 +202,11 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcn32_fwd_kernel(int ntiles, i
 //   dU1 = A^T dZ1                 dW1 += X^T dU1         db1 += colsum(dZ1)
 // every stack is kept [station rows][feature column = lane]; the one contraction over a column index (dU2 W2^T) goes
 // through the wave's LDS tile.  A and A^T fragments are shared by the block's waves through LDS.
-constexpr int BWD_WAVES = 12;   // 143 VGPRs = 3 waves per SIMD: one 12-wave block per CU (8-wave blocks left it at 2 per SIMD: 444 us)
+// waves per backward block (one block per CU): 12 (136 VGPRs, 3 per SIMD; 8-wave blocks left it at 2 per SIMD: 444 us), or 16
+// for S <= 48 from 16384 tiles on (128 VGPRs without scratch, 141 KB of LDS at NT = 3: 247.6 -> 239.3 us at B = 4096; at
+// 6144 tiles the 16-wave grid has 384 -> 256 blocks and is slower, 30.0 vs 25.1 us)
 
-template <int NT>
+template <int NT, int BWD_WAVES>
 __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                                   const float* __restrict__ X,
                                                                   const float* __restrict__ xtail,
@@ -397,9 +399,10 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
   }
 }
 
-int bwd_grid(int ntiles) {
-  int gx = cdiv_i(ntiles, BWD_WAVES);
-  return gx < 1 ? 1 : (gx > 256 ? 256 : gx);   // one 12-wave block per CU, persistent over the tiles
+int bwd_waves_of(int S, int ntiles) { return (S <= 48 && ntiles >= 16384) ? 16 : 12; }
+int bwd_grid(int ntiles, int S) {
+  int gx = cdiv_i(ntiles, bwd_waves_of(S, ntiles));
+  return gx < 1 ? 1 : (gx > 256 ? 256 : gx);   // one block per CU, persistent over the tiles
 }
 
 }  // namespace
@@ -451,22 +454,27 @@ int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const fl
   if (rc0 != WGNN_OK) return rc0;
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   const double by = (double)ntiles * S * 13 * 4.0 * 3.0;
-  const int gx = bwd_grid(ntiles);
-#define BCASE(NT)                                                                                                \
+  const int gx = bwd_grid(ntiles, S);
+  const bool w16 = bwd_waves_of(S, ntiles) == 16;
+#define BLAUNCH(NT, W)                                                                                           \
   PROF_LAUNCH("gcn32_bwd_kernel<" #NT ">", fl, by, st,                                                           \
-              hipLaunchKernelGGL((gcn32_bwd_kernel<NT>), dim3(gx), dim3(64 * BWD_WAVES), 0, st, ntiles, S, A, X, xt, W1, b1, W2, \
+              hipLaunchKernelGGL((gcn32_bwd_kernel<NT, W>), dim3(gx), dim3(64 * W), 0, st, ntiles, S, A, X, xt, W1, b1, W2, \
                                  g, ldg, dg, partial))
+#define BCASE(NT)                                                                                                \
+  if (w16) BLAUNCH(NT, 16);                                                                                      \
+  else BLAUNCH(NT, 12)
   switch ((S + 15) / 16) {
     case 1: BCASE(1); break;
     case 2: BCASE(2); break;
     case 3: BCASE(3); break;
-    case 4: BCASE(4); break;
+    case 4: BLAUNCH(4, 12); break;              // S > 48 never takes the 16-wave form (LDS)
     default: return WGNN_ERR_UNSUPPORTED;
   }
 #undef BCASE
+#undef BLAUNCH
   WGNN_CHECK_LAUNCH();
   if (!dW1) return WGNN_OK;              // deferred: finish.hip reduces the gcn32_bwd_grid(ntiles) partial rows
   return launch_gcn_partial_reduce(partial, gx, dW1, db1, dW2, db2, nullptr, st);
 }
 
-int gcn32_bwd_grid(int ntiles) { return bwd_grid(ntiles); }
+int gcn32_bwd_grid(int ntiles, int S) { return bwd_grid(ntiles, S); }

@@ -12,7 +12,6 @@
 // their time waiting for the next stage), so tiles are as large as LDS and the register file allow to
 // minimise the bytes staged per MFMA.  All MFMAs are v_mfma_f32_16x16x32_f16 (a 32x32x16 rebuild of the
 // NT kernel measured 8 % slower: DESIGN.md section 5).
-#include <cstdlib>
 #include <string>
 
 #include "common.h"
@@ -50,7 +49,7 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
                                                                 float* __restrict__ C, int ldc, int N,
                                                                 const float* __restrict__ s_out_p, int nm, int nsl,
                                                                 size_t bplane, int kc_len, int kc_first,
-                                                                size_t cstride, int accumulate, int a_sm) {
+                                                                size_t cstride, int accumulate) {
   // K chunking (long contractions): this block multiplies columns [k0, k0 + Kp) of the operands, chunk index
   // kc_first + blockIdx.y, into C + blockIdx.y * cstride (split-K partials) or straight into / onto C.
   {
@@ -109,9 +108,9 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     if (pp < PLA * AP) {
       const int plane = pp / AP, blk = pp % AP;
       const int gr = min(m0 + 16 * blk + prow, M - 1);            // rows past M are computed but never stored
-      src[it] = (plane ? Alo : Ahi) + (a_sm ? (size_t)gr * 32 + chunk : (size_t)gr * lda + chunk);
+      src[it] = (plane ? Alo : Ahi) + (size_t)gr * lda + chunk;
       dst[it] = plane * A_PL + blk * 1024;
-      kadv[it] = a_sm ? M * 32 : 32;
+      kadv[it] = 32;
     } else {
       const int q = pp - PLA * AP;
       const int plane = q / BP, blk = q % BP;
@@ -452,7 +451,6 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
   // chain of at most 64 MFMA steps per chunk keeps the summation error at fp32-GEMM level.  With split-K scratch
   // the chunks are blocks of ONE launch (partials summed in fixed order); without, one launch per chunk adds onto C.
   const int nchunks = nt_chunks(Kp), kc_len = nchunks > 1 ? NT_KC : Kp;
-  static const int a_sm = getenv("WGNN_EXP_NT_ASM") ? atoi(getenv("WGNN_EXP_NT_ASM")) : 0;   // EXPERIMENT (timing only)
   const size_t bplane = (size_t)Np * Kp;
   const bool split = kpart && nchunks > 1;
   const int nlaunch = split ? 1 : nchunks;
@@ -468,17 +466,17 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
       PROF_LAUNCH(name.c_str(), fl, by, st,
                   hipLaunchKernelGGL((pgemm_nt_kernel<T, true, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
-                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0, a_sm));
+                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
     else if (x3)
       PROF_LAUNCH(name2.c_str(), fl, by, st,
                   hipLaunchKernelGGL((pgemm_nt_kernel<T, true, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Ahi, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
-                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0, a_sm));
+                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
     else
       PROF_LAUNCH(name16.c_str(), fl, by, st,
                   hipLaunchKernelGGL((pgemm_nt_kernel<T, false, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
-                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0, a_sm));
+                                     nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
     WGNN_CHECK_LAUNCH();
   }
   if (split) {
