@@ -162,10 +162,10 @@ int wgnn_fwd(const wgnn_dims* d, const float* A, const void* X /* d->io */, cons
              void* stash, void* workspace, size_t workspace_bytes, void* stream);
 
 /* wgnn_fwd for a training step whose loss is nn.MSELoss()(Y, labels) (src/main.py:66 + :72): the same Y and stash,
- * and where the forward recurrence holds every h_t in registers anyway (f16x3 / f16, H <= 127) it also reduces
- * (Y - labels) to per-workgroup partial sums of squares and maxima inside the stash, so that
- * wgnn_bwd_mse_part(..., part | 8) needs no pass over Y and the labels for the loss and the range scale.  On every
- * other shape it is exactly wgnn_fwd (and the backward ignores bit 8).  stash must not be NULL. */
+ * and where the forward recurrence holds every h_t in registers anyway (every math mode with H <= 127 / 128; not the
+ * wide-GRU path) it also reduces (Y - labels) to per-workgroup partial sums of squares and maxima inside the stash and
+ * tags them, so that wgnn_bwd_mse_part(..., part | 8) needs no pass over Y and the labels for the loss, the range scale
+ * and dY.  On the wide-GRU path it is exactly wgnn_fwd (and the backward ignores bit 8).  stash must not be NULL. */
 int wgnn_fwd_loss(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* labels,
                   void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -37,6 +37,8 @@ struct Layout {
   size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_kp_f, ws_hc, ws_du, ws_dhz, ws_dhw, ws_hhp_b, ws_kp_b, ws_dc;   // general GRU / GCN scratch
 };
 
+// (min_rows = 64 measured against 128 / 192 / 256 at B*T = 6144 in round 3: fewer, longer K chunks cost the split-K GEMMs more
+// -- 54 -> 78 -> 103 -> 129 us for the two -- than the smaller partial sums save the finish kernel, 16.7 -> 12.2 -> 10.9 us)
 int pick_splitk(size_t BT, int tiles, int target_wgs, int min_rows) {
   int by_rows = (int)(BT / (size_t)min_rows);
   int by_grid = target_wgs / (tiles > 0 ? tiles : 1);
@@ -102,7 +104,10 @@ Layout make_layout(const wgnn_dims* d) {
   }
   L.st_yp = o; o += al((L.BT + 1) * L.Hp);   // two planes of B*T + 1 rows
   L.st_h1 = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
-  L.st_stats = o; o += al(2 * (size_t)grux_blocks(d->B) + 4);      // partial pairs (sum | max) + the tag word (gru_blocks == grux_blocks)
+  {  // partial pairs (sum | max) + the tag word: one pair per workgroup of the forward recurrence (B / 16, or B for gru_small)
+    const size_t nb = L.small ? (size_t)gru_small_blocks(d->B) : (size_t)grux_blocks(d->B);
+    L.st_stats = o; o += al(2 * nb + 4);
+  }
   L.hq = (int)rup(L.H + 1, 16);
   L.st_hprev = o; o += al(L.g32tn ? L.BT * (size_t)L.hq : 0);     // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
   L.stash_floats = o;
@@ -351,7 +356,8 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   if (L.gen_gru)
     rc = launch_gru_gen_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, ws + L.ws_gh, st);
   else if (L.small)   // few windows: one per workgroup instead of sixteen
-    rc = launch_gru_small_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, hprev, L.hq, st);
+    rc = launch_gru_small_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, (float*)Y, gates, hprev, L.hq,
+                              sf ? (const float*)labels : nullptr, sf ? sf + L.st_stats : nullptr, st);
   else if (last)      // the register-resident recurrence writes the read-out itself
     return launch_gru_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, last, nullptr, nullptr, nullptr, nullptr, 0, 1,
                           y_mul, y_add, st);
@@ -514,7 +520,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
   };
   // the recurrence kernel forms dY from the labels itself: the fast f16x3 recurrence always (its statistics pass is
   // cheap), the exact-fp32 register-resident one when the forward left the loss statistics in the stash
-  const bool fused_loss = labels && ((x3 && !L.gen_gru) || (L.rec32 && stats_ready));
+  const bool fused_loss = labels && ((x3 && !L.gen_gru) || ((L.rec32 || L.small) && stats_ready));
   // 16-bit labels / Y: the statistics must come from wgnn_fwd_loss (the stand-alone pass reads fp32 only)
   if (d->io != WGNN_IO_F32 && labels && do_rec && !(fused_loss && stats_ready)) return WGNN_ERR_UNSUPPORTED;
   if (labels && !fused_loss && do_rec) {                   // other kernels: materialise dY in the workspace
@@ -604,7 +610,9 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       rc = launch_gru_gen_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, ws + L.ws_dhz,
                               ws + L.ws_dhw, st);
     else if (L.small)
-      rc = launch_gru_small_bwd(d->B, d->T, d->H, p->w_hh, Y, dY, gates, dGI, dGH, (int)L.Gp, st);
+      rc = launch_gru_small_bwd(d->B, d->T, d->H, p->w_hh, Y, fused_loss ? nullptr : dY, fused_loss ? labels : nullptr, gates,
+                                dGI, dGH, (int)L.Gp, fused_loss ? sf + L.st_stats : nullptr, (int64_t)L.BT * L.H, grad_scale,
+                                loss, status, st);
     else   // register-resident recurrence: dGHn alone when the dW_hh GEMM has the two-source A operand; fused loss
       rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, fused_loss ? nullptr : dY, fused_loss ? labels : nullptr, gates,
                           dGI, (int)L.Gp, L.dghn ? dGH : nullptr, L.dghn ? nullptr : dGH,

@@ -214,12 +214,17 @@ size_t gru_gates_floats(int B, int T, int H);
 int gru_blocks(int B);
 int gru_hn(int H);
 int gru_msplit(int H);
-// small batches (B <= 1024, H <= 128), exact fp32, one window per workgroup with W_hh in registers (gru_small.hip)
+// small batches (B <= 768, H <= 128), exact fp32, one window per workgroup with W_hh in registers (gru_small.hip)
 bool gru_small_supported(int B, int H);
 int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                         float* gates, float* hprev /*nullable: [B*T][hq] rows [h_{t-1} | 1 | 0..]*/, int hq, hipStream_t st);
-int launch_gru_small_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
-                         float* dGI, float* dGH, int ldd, hipStream_t st);
+                         float* gates, float* hprev /*nullable: [B*T][hq] rows [h_{t-1} | 1 | 0..]*/, int hq,
+                         const float* labels /*nullable*/, float* stat_part /*2 * gru_small_blocks(B) + 1 floats*/,
+                         hipStream_t st);
+int gru_small_blocks(int B);
+// exactly one of dY / labels (labels: dY formed in the kernel, loss finalised from stat_part as launch_gru_bwd)
+int launch_gru_small_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
+                         const float* gates, float* dGI, float* dGH, int ldd, const float* stat_part, int64_t n_loss,
+                         float grad_scale, float* loss, unsigned* status, hipStream_t st);
 
 int launch_mse(const float* Y, const float* L, int64_t n, float scale, float* dY, float* loss,
                float* ws, hipStream_t st);

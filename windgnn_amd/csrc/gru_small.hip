@@ -8,7 +8,7 @@
 // Here a workgroup owns ONE window (the WPB template parameter stays 1: more windows per workgroup spill), thread i owns gate row i of W_hh (forward: the row itself, 4H bytes of
 // registers; backward: column j of gate block q, i = q H + j) and the per-step matrix-vector products are plain fp32
 // FMA chains against h / dgh broadcast from LDS: no MFMA tile to fill, ~B workgroups instead of B/16, and a step costs
-// ~H FMAs per thread.  Used when B <= 1024; results are fp32 fmaf chains like gru.hip's (different summation order).
+// ~H FMAs per thread.  Used when B <= 768; results are fp32 fmaf chains like gru.hip's (different summation order).
 #include "common.h"
 
 namespace {
@@ -22,7 +22,14 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
                                                                       const float* __restrict__ Whh,
                                                                       const float* __restrict__ bhh,
                                                                       float* __restrict__ Y, float* __restrict__ gates,
-                                                                      int stage_w, float* __restrict__ hprev, int hq) {
+                                                                      int stage_w, float* __restrict__ hprev, int hq,
+                                                                      const float* __restrict__ Lab,
+                                                                      float* __restrict__ stat_part) {
+  // Lab + stat_part (wgnn_fwd_loss): this workgroup's sum of (h - label)^2 (and max |h - label|) goes to
+  // stat_part[blockIdx.x] / stat_part[gridDim.x + blockIdx.x], the tag behind them says so; a forward without labels
+  // clears the tag (as gru.hip / grux.hip)
+  if (stat_part && blockIdx.x == 0 && threadIdx.x == 0) stat_part[2 * gridDim.x] = Lab ? WGNN_STATS_TAG : 0.f;
+  float ssum = 0.f, smax = 0.f;
   // hprev (nullable): rows [h_{t-1} | 1 | 0..] of width hq with 16-byte aligned rows, the B operand of the dW_hh GEMM
   // (gemm32.hip) -- written here instead of by a pass of its own over Y
   if (hprev) {
@@ -70,8 +77,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
   const int j = threadIdx.x;
   const bool jv = j < H;
   const int jc = jv ? j : H - 1;
-  float gi[WPB][3], gin[WPB][3];
-  auto load_gi = [&](int t, float (&dst)[WPB][3]) {
+  float gi[WPB][4], gin[WPB][4];                                      // [3] = the label of the step (fused loss)
+  auto load_gi = [&](int t, float (&dst)[WPB][4]) {
     const int tc = t < T ? t : T - 1;
 #pragma unroll
     for (int wdw = 0; wdw < WPB; ++wdw) {
@@ -80,6 +87,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
       dst[wdw][0] = row[jc];
       dst[wdw][1] = row[H + jc];
       dst[wdw][2] = row[2 * H + jc];
+      dst[wdw][3] = Lab ? Lab[((size_t)b * T + tc) * H + jc] : 0.f;
     }
   };
   load_gi(0, gi);
@@ -122,6 +130,11 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
           const size_t bt = (size_t)b * T + t;
           Y[bt * H + j] = hnew;
           if (hprev && t + 1 < T) hprev[(bt + 1) * hq + j] = hnew;
+          if (Lab) {
+            const float dl = hnew - gi[wdw][3];
+            ssum = fmaf(dl, dl, ssum);
+            smax = fmaxf(smax, fabsf(dl));
+          }
           if (gates)   // one 16-byte record (r, z, n, gh_n) per element, [bt][j][4]
             *(f32x4*)(gates + (bt * H + j) * 4) = f32x4{rg, zg, ng, ghn};
         }
@@ -131,7 +144,29 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
 #pragma unroll
     for (int wdw = 0; wdw < WPB; ++wdw)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gi[wdw][c] = gin[wdw][c];
+      for (int c = 0; c < 4; ++c) gi[wdw][c] = gin[wdw][c];
+  }
+  if (Lab) {   // fixed order: lanes (xor tree), then the waves
+    __shared__ float red[2][SMALL_THREADS / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ssum += __shfl_xor(ssum, o, 64);
+      smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = ssum;
+      red[1][threadIdx.x >> 6] = smax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = 0.f, m = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        a += red[0][w];
+        m = fmaxf(m, red[1][w]);
+      }
+      stat_part[blockIdx.x] = a;
+      stat_part[gridDim.x + blockIdx.x] = m;
+    }
   }
 }
 
@@ -147,7 +182,28 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
                                                                       const float* __restrict__ dY,
                                                                       const float* __restrict__ gates,
                                                                       float* __restrict__ dGI, float* __restrict__ dGH,
-                                                                      int ldd) {
+                                                                      int ldd, const float* __restrict__ Lab,
+                                                                      float coef_lab, const float* __restrict__ stat_part,
+                                                                      int nstat, float inv_n, float* __restrict__ loss_out,
+                                                                      unsigned* status) {
+  // Lab: dY = (Y - Lab) * coef_lab is formed here (Y[b, t] is the h_prev this kernel loads for step t + 1 anyway);
+  // stat_part: workgroup 0 finalises loss = (sum of the forward's nstat partial sums) / n in a fixed order
+  if (stat_part && blockIdx.x == 0) {
+    __shared__ float sred[SMALL_THREADS / 64];
+    float a = 0.f;
+    for (int e = threadIdx.x; e < nstat; e += blockDim.x) a += stat_part[e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += sred[w];
+      const bool tagged = stat_part[2 * nstat] == WGNN_STATS_TAG;
+      loss_out[0] = tagged ? a * inv_n : __builtin_nanf("");
+      if (!tagged && status) atomicOr(status, WGNN_STATUS_NO_LOSS_STATS);
+    }
+  }
   __shared__ __attribute__((aligned(16))) float dghs[WPB][3 * HMAX];  // dgh_t, gate-major with stride HMAX, zero pads
   __shared__ float part[WPB][3][HMAX];                                 // the three gate blocks' shares of dgh W_hh
   const int i = threadIdx.x;
@@ -181,7 +237,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
       const size_t bt = (size_t)b * T + tc;
       const int jj = i;
       const f32x4 gq = *(const f32x4*)(gates + (bt * H + jj) * 4);   // the forward's (r, z, n, gh_n) record
-      s[wdw].dy = dY[bt * H + jj];
+      s[wdw].dy = Lab ? Lab[bt * H + jj] : dY[bt * H + jj];          // the label, or dY itself
       s[wdw].r = gq[0];
       s[wdw].z = gq[1];
       s[wdw].n = gq[2];
@@ -191,9 +247,13 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
     }
   };
   load_step(T - 1, cur);
-  float dhn[WPB], dhz[WPB];
+  float dhn[WPB], dhz[WPB], ycur[WPB];                                // ycur = Y[b, t]
 #pragma unroll
-  for (int wdw = 0; wdw < WPB; ++wdw) dhn[wdw] = 0.f;
+  for (int wdw = 0; wdw < WPB; ++wdw) {
+    dhn[wdw] = 0.f;
+    const int b = b0 + wdw < B ? b0 + wdw : B - 1;
+    ycur[wdw] = (Lab && own) ? Y[((size_t)b * T + T - 1) * H + i] : 0.f;
+  }
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
@@ -202,7 +262,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
 #pragma unroll
       for (int wdw = 0; wdw < WPB; ++wdw) {
         const int b = b0 + wdw;
-        const float dh = cur[wdw].dy + dhn[wdw];
+        const float dh = (Lab ? (ycur[wdw] - cur[wdw].dy) * coef_lab : cur[wdw].dy) + dhn[wdw];
         const float rg = cur[wdw].r, zg = cur[wdw].z, ng = cur[wdw].n;
         const float dn = dh * (1.f - zg);
         const float dz = dh * (cur[wdw].hp - ng);
@@ -254,7 +314,10 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
         dhn[wdw] = dhz[wdw] + ((part[wdw][0][i] + part[wdw][1][i]) + part[wdw][2][i]);
     }
 #pragma unroll
-    for (int wdw = 0; wdw < WPB; ++wdw) cur[wdw] = nxt[wdw];
+    for (int wdw = 0; wdw < WPB; ++wdw) {
+      ycur[wdw] = cur[wdw].hp;                                        // Y[b, t - 1]
+      cur[wdw] = nxt[wdw];
+    }
   }
 }
 
@@ -262,8 +325,9 @@ int pick_wpb(int B) { return 1; }   // 2 and 4 windows per workgroup spill at H 
 
 }  // namespace
 
-// B workgroups of ~25 us each: up to 1024 windows that beats gru.hip's B/16 workgroups of 126 / 163 us
-bool gru_small_supported(int B, int H) { return H >= 1 && H <= 128 && B <= 1024; }
+// B workgroups of ~25-40 us each on 256 CUs: 38 + 39 us at B = 256, 128 + 151 us at B = 1024, against gru.hip's B/16
+// workgroups of 113 + 117 us whatever B <= 4096 is (round 3: register-resident W_hh): the one-window form wins up to ~768
+bool gru_small_supported(int B, int H) { return H >= 1 && H <= 128 && B <= 768; }
 
 #define SMALL_DISPATCH(KERNEL, ...)                                                                              \
   do {                                                                                                           \
@@ -277,40 +341,47 @@ bool gru_small_supported(int B, int H) { return H >= 1 && H <= 128 && B <= 1024;
 
 template <int HMAX>
 static int launch_small_fwd_t(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                              float* gates, float* hprev, int hq, hipStream_t st) {
+                              float* gates, float* hprev, int hq, const float* labels, float* stat_part, hipStream_t st) {
   const size_t wbytes = (size_t)3 * H * H * sizeof(float);
   const int stage_w = wbytes <= 140 * 1024;
   const size_t smem = stage_w ? wbytes : 0;
   static std::atomic<unsigned long long> done{0};
   if (ensure_dyn_smem((const void*)gru_small_fwd_kernel<HMAX, 1>, 140 * 1024, done) != WGNN_OK) return WGNN_ERR_HIP;
   hipLaunchKernelGGL((gru_small_fwd_kernel<HMAX, 1>), dim3(B), dim3(cdiv_i(3 * H, 64) * 64), smem, st, B, T, H, GI, ldgi,
-                     Whh, bhh, Y, gates, stage_w, hprev, hq);
+                     Whh, bhh, Y, gates, stage_w, hprev, hq, labels, stat_part);
   return WGNN_OK;
 }
 
 int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
-                         float* gates, float* hprev, int hq, hipStream_t st) {
+                         float* gates, float* hprev, int hq, const float* labels, float* stat_part, hipStream_t st) {
   if (!gru_small_supported(B, H)) return WGNN_ERR_UNSUPPORTED;
   if (hprev && (hq < H + 1 || hq % 4 != 0)) return WGNN_ERR_SHAPE;
   const double bt = (double)B * T;
   int rc = WGNN_OK;
   PROF_LAUNCH("gru_small_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0) + (hprev ? hq : 0)), st,
-              rc = H <= 32   ? launch_small_fwd_t<32>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st)
-                   : H <= 64 ? launch_small_fwd_t<64>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st)
-                   : H <= 96 ? launch_small_fwd_t<96>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st)
-                   : H <= 112 ? launch_small_fwd_t<112>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st)
-                              : launch_small_fwd_t<128>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, st));
+              rc = H <= 32   ? launch_small_fwd_t<32>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                   : H <= 64 ? launch_small_fwd_t<64>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                   : H <= 96 ? launch_small_fwd_t<96>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                   : H <= 112 ? launch_small_fwd_t<112>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                              : launch_small_fwd_t<128>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st));
   if (rc != WGNN_OK) return rc;
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
 
-int launch_gru_small_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* gates,
-                         float* dGI, float* dGH, int ldd, hipStream_t st) {
+int gru_small_blocks(int B) { return B; }        // workgroups of the forward = MSE partial pairs it writes with labels
+
+int launch_gru_small_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
+                         const float* gates, float* dGI, float* dGH, int ldd, const float* stat_part, int64_t n_loss,
+                         float grad_scale, float* loss, unsigned* status, hipStream_t st) {
   if (!gru_small_supported(B, H)) return WGNN_ERR_UNSUPPORTED;
+  if ((dY == nullptr) == (labels == nullptr)) return WGNN_ERR_SHAPE;
+  if (stat_part && (!labels || !loss)) return WGNN_ERR_NULL;
   const double bt = (double)B * T;
+  const float inv_n = 1.0f / (float)n_loss, coef = 2.0f * grad_scale / (float)n_loss;
   PROF_LAUNCH("gru_small_bwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (4 * H + 2 * H + 6 * H), st,
-              SMALL_DISPATCH(gru_small_bwd_kernel, B, T, H, Whh, Y, dY, gates, dGI, dGH, ldd));
+              SMALL_DISPATCH(gru_small_bwd_kernel, B, T, H, Whh, Y, dY, gates, dGI, dGH, ldd, labels, coef, stat_part,
+                             gru_small_blocks(B), inv_n, loss, status));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
