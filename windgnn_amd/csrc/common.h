@@ -140,7 +140,7 @@ size_t gcn32_bwd_partial_floats(int ntiles);
 int launch_gcn32_fwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
                      const float* W2, const float* b2, float* g, int ldg, float* xtail_scratch, hipStream_t st);
 int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* g, int ldg, const float* dg, float* dW1, float* db1, float* dW2,
+                     const float* W2, const float* g, int ldg, const float* dg, int ld_dg, float* dW1, float* db1, float* dW2,
                      float* db2, float* partial, float* xtail_scratch, hipStream_t st);
 // register-chained split-fp16 variants (gcnx.hip)
 size_t gcnx2_bwd_partial_floats(int ntiles);
@@ -150,8 +150,8 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io /*
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, void* xtail_scratch,
                      hipStream_t st);   // xtail_scratch: >= S*13 + 1 elements of workspace when S*13 is odd
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
-                     const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
-                     int scale_in, float* partial, bool x3, void* xtail_scratch, hipStream_t st);
+                     const float* W2, const void* g_planes, int ldg, const float* dg, int ld_dg /*row pitch of dg*/,
+                     const float* scales, int scale_in, float* partial, bool x3, void* xtail_scratch, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
                          int Rp, int Cp, unsigned* status, hipStream_t st);

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
                                                                   const float* __restrict__ b1,
                                                                   const float* __restrict__ W2,
                                                                   const float* __restrict__ gact, int ld_g,
-                                                                  const float* __restrict__ dg,
+                                                                  const float* __restrict__ dg, int ld_dg,
                                                                   float* __restrict__ partial) {
   constexpr int SP = 16 * NT;
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
   if (wave_id < ntiles) {
     XLOAD(wave_id);
     gload_pairs<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
-    gload_pairs<NP>(dr, dg + (size_t)wave_id * I, lane, I);
+    gload_pairs<NP>(dr, dg + (size_t)wave_id * ld_dg, lane, I);
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     asm volatile("" ::: "memory");                             // keep the fragment reads in LDS (no hoisting into VGPRs)
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
       const size_t nt = (size_t)(tile + nwaves);
       XLOAD(tile + nwaves);
       gload_pairs<NP>(gr, gact + nt * ld_g, lane, I);
-      gload_pairs<NP>(dr, dg + nt * I, lane, I);
+      gload_pairs<NP>(dr, dg + nt * ld_dg, lane, I);
     }
     // ---- recompute U1 [s][f'], H1 [s][f]
     f32x4 U[NT];
@@ -447,7 +447,7 @@ int launch_gcn32_fwd(int ntiles, int S, const float* A, const float* X, const fl
 }
 
 int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const float* W1, const float* b1,
-                     const float* W2, const float* g, int ldg, const float* dg, float* dW1, float* db1, float* dW2,
+                     const float* W2, const float* g, int ldg, const float* dg, int ld_dg, float* dW1, float* db1, float* dW2,
                      float* db2, float* partial, float* xtail_scratch, hipStream_t st) {
   const float* xt;
   const int rc0 = xtail32_copy(X, ntiles, S, xtail_scratch, st, &xt);
@@ -459,7 +459,7 @@ int launch_gcn32_bwd(int ntiles, int S, const float* A, const float* X, const fl
 #define BLAUNCH(NT, W)                                                                                           \
   PROF_LAUNCH("gcn32_bwd_kernel<" #NT ">", fl, by, st,                                                           \
               hipLaunchKernelGGL((gcn32_bwd_kernel<NT, W>), dim3(gx), dim3(64 * W), 0, st, ntiles, S, A, X, xt, W1, b1, W2, \
-                                 g, ldg, dg, partial))
+                                 g, ldg, dg, ld_dg, partial))
 #define BCASE(NT)                                                                                                \
   if (w16) BLAUNCH(NT, 16);                                                                                      \
   else BLAUNCH(NT, 12)

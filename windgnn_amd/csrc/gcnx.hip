@@ -450,8 +450,9 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
                                                        const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const _Float16* __restrict__ gact, int ld_g,
-                                                       const float* __restrict__ dg, const float* __restrict__ scales,
-                                                       int scale_in, float* __restrict__ partial) {
+                                                       const float* __restrict__ dg, int ld_dg,
+                                                       const float* __restrict__ scales, int scale_in,
+                                                       float* __restrict__ partial) {
   constexpr int KS = (NT + 1) / 2;
   constexpr int NF = NT * KS;
   constexpr int SP = 16 * NT;
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
   if (wave_id < ntiles) {
     XLOAD(wave_id);
     gload_pairs_h<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
-    gload_pairs<NP>(dr, dg + (size_t)wave_id * I, lane, I);
+    gload_pairs<NP>(dr, dg + (size_t)wave_id * ld_dg, lane, I);
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     asm volatile("" ::: "memory");   // keep the A / A^T fragment reads in LDS (no hoisting into 96 VGPRs)
@@ -550,7 +551,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
       const size_t nt = (size_t)(tile + nwaves);
       XLOAD(tile + nwaves);
       gload_pairs_h<NP>(gr, gact + nt * ld_g, lane, I);
-      gload_pairs<NP>(dr, dg + nt * I, lane, I);
+      gload_pairs<NP>(dr, dg + nt * ld_dg, lane, I);
     }
     // ---- recompute U1, H1 [s][f]
     f32x4 U[NT];
@@ -754,8 +755,9 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, c
 }
 
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
-                     const float* W2, const void* g_planes, int ldg, const float* dg, const float* scales,
+                     const float* W2, const void* g_planes, int ldg, const float* dg, int ld_dg, const float* scales,
                      int scale_in, float* partial, bool x3, void* xtail_scratch, hipStream_t st) {
+  if (ld_dg < S * 13 || (ld_dg & 1)) return WGNN_ERR_SHAPE;      // rows of dg: 8-byte aligned pairs
   int rc0;
   const void* xt = xtail_copy(X, ntiles, S, io, xtail_scratch, st, &rc0);
   if (rc0 != WGNN_OK) return rc0;
@@ -767,7 +769,7 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
 #define BWD_LAUNCH(NT, X3V, IOV, NAME)                                                                            \
   PROF_LAUNCH(NAME, fl, by, st,                                                                                   \
               hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV>), grid, dim3(64 * bwd_waves(NT, X3V)), 0, st, ntiles, S, A, X, xt, io, \
-                                 W1, b1, W2, g, ldg, dg, scales, scale_in, partial))
+                                 W1, b1, W2, g, ldg, dg, ld_dg, scales, scale_in, partial))
 #define BWD_CASE(NT)                                                                                              \
   if (x3 && !io) BWD_LAUNCH(NT, true, false, "gcnx_bwd_kernel<" #NT ">");                                         \
   else if (x3) BWD_LAUNCH(NT, true, true, "gcnx_bwd_kernel<" #NT ">");                                            \
