@@ -23,20 +23,26 @@ from windgnn_amd import _lib as L
 lib = C.CDLL(%(so)r)
 for name, (res, args) in L.EXPORTS.items():
     fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
-assert lib.wgnn_version() >= 110
+assert lib.wgnn_version() >= 120
 for st in range(-9, 2):
     assert lib.wgnn_strerror(st)
 n = 0
 for B in (1, 2, 15, 16, 17, 256, 4096):
     for (S, H) in ((1, 1), (3, 9), (7, 21), (34, 102), (48, 33), (64, 127), (20, 200), (65, 12), (4096, 12288)):
-        for math in (0, 1, 2, 7):
+        for math in (0, 1, 2, 3, 7):
             for fmt, nnz in ((0, 0), (1, 9 * S), (1, 0), (3, 0)):
                 for io in (0, 1, 2, 5):
                     d = L.Dims(B, 24, S, 13, H, math, fmt, nnz, io)
                     w, s = lib.wgnn_workspace_bytes(C.byref(d)), lib.wgnn_stash_bytes(C.byref(d))
                     assert (w == 0) == (s == 0), (B, S, H, math, fmt, io)
                     n += 1
-                    p, g = L.Params(), L.Grads()
+                    p, g, ad = L.Params(), L.Grads(), L.Adam()
+                    pb = lib.wgnn_prepared_bytes(C.byref(d))
+                    assert pb == 0 or w > 0
+                    ad.step = 1
+                    for which, adam in ((6, None), (4, None), (2, None), (0, ad), (6, ad), (8, None), (0, None)):
+                        assert lib.wgnn_finish(C.byref(d), C.byref(p), C.byref(g), which, C.byref(adam) if adam else None, None, 0, None) < 0
+                    assert lib.wgnn_prepare_weights(C.byref(d), C.byref(p), None, 0, None) < 0
                     for fn in (lambda: lib.wgnn_fwd(C.byref(d), None, None, C.byref(p), None, None, None, 0, None),
                                lambda: lib.wgnn_fwd_loss(C.byref(d), None, None, C.byref(p), None, None, None, None, 0, None),
                                lambda: lib.wgnn_fwd_last(C.byref(d), None, None, C.byref(p), 0.0, 1.0, None, None, 0, None),

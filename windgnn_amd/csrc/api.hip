@@ -132,8 +132,8 @@ Layout make_layout(const wgnn_dims* d) {
     L.sk_hh = L.g32tn ? pick_splitk(L.BT, gemm32_tn_tiles(L.m_hh, (int)L.H + 1), 256, 64)
                     : pick_splitk(L.BT, gemm_f32_tiles((int)L.G3, (int)L.H + 1), 1024, 128);
   }
-  size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.I + 1);
-  size_t part_hh = (size_t)L.sk_hh * (size_t)L.m_hh * (L.H + 1);
+  size_t part_ih = (size_t)L.sk_ih * L.G3 * (L.g32tn ? (size_t)gemm32_tn_pitch((int)L.I + 1) : L.I + 1);
+  size_t part_hh = (size_t)L.sk_hh * (size_t)L.m_hh * (L.g32tn ? (size_t)gemm32_tn_pitch((int)L.H + 1) : L.H + 1);
   if (x3) {
     part_ih = pgemm_tn_partial_floats((int)L.G3, (int)L.I + 1, L.sk_ih);
     part_hh = pgemm_tn_partial_floats(L.m_hh, (int)L.H + 1, L.sk_hh);
@@ -190,6 +190,8 @@ void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float
     hh.splitk = L.sk_hh;
     hh.Nout = (int)L.H + 1; hh.ncols = (int)L.H;
     hh.Mgemm = L.m_hh;
+    ih.pitch = L.g32tn ? gemm32_tn_pitch(ih.Nout) : ih.Nout;
+    hh.pitch = L.g32tn ? gemm32_tn_pitch(hh.Nout) : hh.Nout;
     if (L.dghn) { hh.msplit = L.msplit; hh.rows1 = 2 * d->H; }     // GEMM rows [dGI_r | dGI_z | pad | dGHn]
     if (L.x3) {
       pgemm_tn_geom((int)L.G3, ih.Nout, &ih.T, &ih.nNb, &ih.ntiles);

@@ -104,6 +104,7 @@ int launch_pad_weight(const float* W, int R, int C, int transpose, const float* 
                       hipStream_t st);
 int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, hipStream_t st);
 int gemm32_tn_tiles(int Mo, int No);
+int gemm32_tn_pitch(int No);
 // A2 != null: GEMM columns m >= msplit of the A operand come from A2 (column m - msplit, row stride lda2)
 int launch_gemm32_tn(const float* A, int lda, const float* B, int ldb, int K, int splitk, float* P, int Mo, int No,
                      const float* A2, int lda2, int msplit, hipStream_t st);
@@ -240,6 +241,7 @@ struct FinSeg {                // one split-K weight-gradient product: C[Mout][n
   int kind;                    // 0: nothing to reduce; 1: plain [z][Mout][Nout]; 2: pgemm_tn_kernel's layout
   int T, nNb, ntiles;          // kind 2
   int Mout, Nout, ncols;
+  int pitch;                   // kind 1: floats between partial rows (Nout, or the LDS-DMA TN kernel's 64-byte aligned pitch)
   int Mgemm;                   // rows of the GEMM that wrote the partials (= Mout unless its A operand had two sources)
   int msplit, rows1;           // two-source A operand: GEMM row m < rows1 is weight row m, m >= msplit is rows1 + m - msplit
   int scaled;                  // the partials are in units scaled by scales[0]: multiply by scales[1]

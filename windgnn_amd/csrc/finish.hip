@@ -98,7 +98,7 @@ __device__ __forceinline__ void seg_tn(const FinishArgs& a, const FinSeg& s, int
 template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
 __device__ __forceinline__ void seg_plain(const FinishArgs& a, const FinSeg& s, int tw, int tb, int blk, bool& bad_g,
                                           bool& bad_w) {
-  const size_t MN = (size_t)s.Mgemm * s.Nout;                        // Mgemm: rows of the GEMM that wrote the partials
+  const size_t MN = (size_t)s.Mgemm * s.pitch;                       // Mgemm: rows of the GEMM that wrote the partials
   const size_t i = (size_t)blk * 256 + threadIdx.x;
   if (i >= MN) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
@@ -116,8 +116,9 @@ __device__ __forceinline__ void seg_plain(const FinishArgs& a, const FinSeg& s, 
   for (; z < s.splitk; ++z) s0 += s.partial[(size_t)z * MN + i];
   float v = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   if (s.scaled) v *= a.scales[1];
-  int m = (int)(i / s.Nout);
-  const int n = (int)(i % s.Nout);
+  int m = (int)(i / s.pitch);
+  const int n = (int)(i % s.pitch);
+  if (n >= s.Nout) return;                                            // alignment padding of the partial rows
   if (s.msplit > 0) {                                                 // two-source A operand: GEMM rows -> weight rows
     if (m >= s.msplit) m = s.rows1 + (m - s.msplit);
     else if (m >= s.rows1) return;
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(256) finish_kernel(const FinishArgs a) {
 
 int finish_seg_blocks(const FinSeg& s) {
   if (s.kind == 2) return (int)((size_t)s.ntiles * TN_WAVES * 5 * s.T);      // slab4 / 64
-  if (s.kind == 1) return (int)(((size_t)s.Mgemm * s.Nout + 255) / 256);
+  if (s.kind == 1) return (int)(((size_t)s.Mgemm * s.pitch + 255) / 256);
   return 0;
 }
 

@@ -215,7 +215,8 @@ __global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __
     compute(cur);
   }
 
-  float* Pz = P + (size_t)z * Mo * No;
+  const int pitch = (No + 15) & ~15;                               // rows of the partials start 64-byte aligned (gemm32_tn_pitch)
+  float* Pz = P + (size_t)z * Mo * pitch;
 #pragma unroll
   for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 80 * wm + 16 * i + 4 * kq + r;
-        if (row < Mo) Pz[(size_t)row * No + col] = acc[i][j][r];
+        if (row < Mo) Pz[(size_t)row * pitch + col] = acc[i][j][r];
       }
     }
 }
@@ -353,7 +354,8 @@ int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, fl
 }
 
 // Workgroup tiles of the split-K product (for the split-K choice) and the product itself:
-// P[z][Mo][No] = sum over K chunk z of A[k][m] B[k][n]; rows of A and B 16-byte aligned; reduced by finish.hip (plain [z][Mo][No] layout).
+// P[z][Mo][gemm32_tn_pitch(No)] = sum over K chunk z of A[k][m] B[k][n]; rows of A and B 16-byte aligned; reduced by finish.hip (plain [z][Mo][No] layout).
+int gemm32_tn_pitch(int No) { return (No + 15) & ~15; }           // row pitch of P[z][Mo][pitch]
 int gemm32_tn_tiles(int Mo, int No) {
   int nNb, T;
   tn_shape(No, nNb, T);
