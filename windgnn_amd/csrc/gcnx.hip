@@ -95,6 +95,15 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
       : "v"(hi), "v"(x0), "v"(x1));
   lo = cvt2(t0, t1);
 }
+// the same split, also handing back the differences x - hi (for the copy-out's range check: -inf / NaN where x left fp16's range)
+__device__ __forceinline__ void split2t(float x0, float x1, unsigned& hi, unsigned& lo, float& t0, float& t1) {
+  hi = cvt2(x0, x1);
+  asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(t0), "=&v"(t1)
+      : "v"(hi), "v"(x0), "v"(x1));
+  lo = cvt2(t0, t1);
+}
 template <bool X3>
 __device__ __forceinline__ Frag split_vals(const float (&x)[8]) {
   typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -186,6 +195,17 @@ struct PairMap {
       const int e = 2 * (lane + 64 * k);
       o0[k] = e < I ? (e / F13) * XS + (e % F13) : dump;
       o1[k] = e + 1 < I ? ((e + 1) / F13) * XS + ((e + 1) % F13) : dump;
+    }
+  }
+  // read map of the forward's copy-out: element I of the padded row reads a slot that holds 1.0 (the ones column of the
+  // g planes), later elements a slot that holds 0 -- two pad words of row 0 no tile store touches -- so the copy-out needs
+  // no selects (4 v_cndmask per pair before)
+  __device__ __forceinline__ void init_out(int lane, int I, int ones, int zero) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int e = 2 * (lane + 64 * k);
+      o0[k] = e < I ? (e / F13) * XS + (e % F13) : (e == I ? ones : zero);
+      o1[k] = e + 1 < I ? ((e + 1) / F13) * XS + ((e + 1) % F13) : (e + 1 == I ? ones : zero);
     }
   }
 };
@@ -324,10 +344,14 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       bb2[r] = f < F13 ? b2[f] : 0.f;
     }
   }
-  PairMap<NP> map;
+  PairMap<NP> map, omap;
   map.init(lane, I, SP * XS - 1);
+  constexpr int ONES = 16, ZERO = 17;                 // pad words of row 0 (columns 16, 17 of XS = 20): never a store target
+  omap.init_out(lane, I, ONES, ZERO);
+  if (lane == 0) ob[ONES] = 1.f;                      // ob[ZERO] stays 0 from the clear above
   const int npairs = (I + 1) / 2;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 bias1 = {bb1[0], bb1[1], bb1[2], bb1[3]}, bias2 = {bb2[0], bb2[1], bb2[2], bb2[3]};   // accumulator seeds
   const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
 
@@ -361,7 +385,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
     f32x4 Ht[NT];                                    // H1^T column-tile n: [f][s = 16n + c]
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      f32x4 acc = zero4;
+      f32x4 acc = bias1;                         // the bias seeds the accumulator (one v_add per value less)
       f32x4 acc16 = zero4;                       // the K = 16 step has its own accumulator (MIXED_FORMS)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -372,7 +396,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       if (X3 && (NT & 1)) acc += acc16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        Ht[n][r] = relu_nan(acc[r] + bb1[r]);
+        Ht[n][r] = relu_nan(acc[r]);
       }
     }
 #pragma unroll
@@ -381,7 +405,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
     for (int ks = 0; ks < KS; ++ks) UF[ks] = (2 * ks + 1 < NT) ? frag_of<X3>(U[2 * ks], U[2 * ks + 1]) : frag_half<X3>(U[2 * ks]);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      f32x4 acc = zero4;
+      f32x4 acc = bias2;
       f32x4 acc16 = zero4;                       // the K = 16 step has its own accumulator (MIXED_FORMS)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -393,7 +417,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = relu_nan(acc[r] + bb2[r]);
+        v[r] = relu_nan(acc[r]);
       }
       *(f32x4*)(ob + (16 * n + c) * XS + 4 * g) = v;           // g^T[f' = 4g..4g+3][s] -> staged [s][f']
     }
@@ -408,18 +432,15 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         if (64 * k < ldp / 2) {
-          const int p = lane + 64 * k, e = 2 * p;
-          float v0 = ob[map.o0[k]], v1 = ob[map.o1[k]];          // dump slot for e >= I: value unused
-          v0 = e < I ? v0 : (e == I ? 1.f : 0.f);
-          v1 = e + 1 < I ? v1 : (e + 1 == I ? 1.f : 0.f);
-          h2 hi, lo;
-          hi[0] = (_Float16)v0; hi[1] = (_Float16)v1;
-          const float d0 = v0 - (float)hi[0], d1 = v1 - (float)hi[1];   // -inf where the value rounded to fp16's inf
+          const int p = lane + 64 * k;
+          const float v0 = ob[omap.o0[k]], v1 = ob[omap.o1[k]];   // the tile, then 1.0 at column I, then zeros
+          unsigned hi, lo;
+          float d0, d1;                                            // v - hi: -inf where the value rounded to fp16's inf
+          split2t(v0, v1, hi, lo, d0, d1);
           chk = __builtin_fmaf(d0, 0.f, __builtin_fmaf(d1, 0.f, chk));
-          lo[0] = (_Float16)d0; lo[1] = (_Float16)d1;
           if (p < ldp / 2) {
-            dh[p] = __builtin_bit_cast(unsigned, hi);
-            if (X3) dl[p] = __builtin_bit_cast(unsigned, lo);
+            dh[p] = hi;
+            if (X3) dl[p] = lo;
           }
         }
       }
