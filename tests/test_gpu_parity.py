@@ -1200,3 +1200,47 @@ def test_f16x3g_is_f16x3_below_4096_rows_and_within_tolerance_above():
         for k in PARAM_KEYS:
             assert rel_to_max(res["f16x3g"][2][k], go[k]) <= 2e-5, k                # 5x inside G_TOL
             assert rel_to_max(res["f16x3"][2][k], go[k]) <= 5e-6, k
+
+
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+def test_trainstep_notices_parameters_written_behind_its_back(math):
+    """TrainStep keeps the staged W_ih images (wgnn_params.prepared) across steps; wgnn_finish keeps them current.  When
+    someone else writes the parameters -- load_state_dict, an in-place op on a Parameter or on the flat buffer -- torch's
+    version counters change and the images are rebuilt; after a write torch cannot see (p.data.copy_) refresh() does it.
+    In every case the next step must equal the step of a fresh TrainStep built from the new parameters, bit for bit."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.trainer import TrainStep
+    dev = _dev()
+    fx = load_fixture("f3b_s34_t24_b4_rand")
+    A = torch.from_numpy(fx["A"]).to(dev)
+    X = torch.from_numpy(fx["X"]).repeat(43, 1, 1, 1).to(dev)          # B = 172: 4128 rows, the big fp32 GEMMs use the images too
+    L = torch.from_numpy(fx["L"]).repeat(43, 1, 1).to(dev)
+    other = orc.init_params(34, 13, 102, seed=77)
+
+    def fresh(params):
+        t = TrainStep(_model_from(params, 34, 102, math))
+        loss, Y = t.step(A, X, L)
+        return float(loss), Y.clone(), t.flat_p.clone()
+
+    want = fresh(other)
+    for how in ("load_state_dict", "parameter_copy_", "flat_copy_", "data_copy_ + refresh"):
+        model = _model_from(fx["params"], 34, 102, math)
+        tr = TrainStep(model)
+        tr.step(A, X, L)                                                 # images built from the first parameters
+        if how == "load_state_dict":
+            model.load_state_dict({k: v.clone() for k, v in other.items()})
+        elif how == "parameter_copy_":
+            with torch.no_grad():
+                for k, q in model.named_parameters():
+                    q.copy_(other[k].to(dev))
+        elif how == "flat_copy_":
+            tr.flat_p.copy_(torch.cat([other[k].reshape(-1) for k in PARAM_KEYS]).to(dev))
+        else:
+            for k, q in model.named_parameters():
+                q.data.copy_(other[k].to(dev))
+            tr.refresh()
+        tr.exp_avg.zero_(); tr.exp_avg_sq.zero_(); tr.steps = 0          # optimiser state of a fresh run
+        loss, Y = tr.step(A, X, L)
+        assert float(loss) == want[0], how
+        assert torch.equal(Y, want[1]), how
+        assert torch.equal(tr.flat_p, want[2]), how
