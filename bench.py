@@ -418,7 +418,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": DTYPE_LABEL[args.math] +
+            "dtype": (DTYPE_LABEL[args.math] if not (args.workload == "c5" and args.math == "f16x3g")
+                      else "f16x3g (= f16x3 on the wide-GRU / CSR path: every product three-pass split fp16)") +
                      ("" if args.io == "fp32" else " math, %s I/O" % args.io),
             "data": "synthetic",
             "config": {"workload": "S=%d stations%s, T=24, F=13, H=%d, B=%d windows/GPU; step = forward + MSE + "
