@@ -1244,3 +1244,32 @@ def test_trainstep_notices_parameters_written_behind_its_back(math):
         assert float(loss) == want[0], how
         assert torch.equal(Y, want[1]), how
         assert torch.equal(tr.flat_p, want[2]), how
+
+
+def test_f16x3g_training_trajectory_at_full_batch_tracks_exact_fp32_like_strict_f16x3():
+    """bench.py's mode at bench.py's size (B = 4096: the single-plane gate gradients and the two / one-pass backward GEMMs
+    are active): 12 optimiser steps on one fixed batch in exact fp32, strict f16x3 and f16x3g from the same initial
+    parameters.  The loss after every step must agree with exact fp32's to 2e-5 relative in both split modes, and f16x3g
+    must sit within 1e-6 of strict f16x3 (observed over 30 steps, profiles/r3_trajectory_modes_b4096.txt: both <= 4.1e-6
+    of fp32 over the first 12 steps, <= 2.3e-5 over 30; the two split modes differ by <= 2e-7)."""
+    from windgnn_amd import GCN_GRU
+    from windgnn_amd.trainer import TrainStep
+    from conftest import GOLDEN
+    import numpy as np, os
+    dev = _dev()
+    S, T, B, H = 34, 24, 4096, 102
+    A = torch.from_numpy(np.load(os.path.join(GOLDEN, "graph_7_34.npz"))["A34"]).float().to(dev)
+    g = torch.Generator().manual_seed(1234)
+    X = torch.rand(B, T, S, 13, generator=g).to(dev)
+    L = torch.rand(B, T, H, generator=g).to(dev)
+    traj = {}
+    for math in ("f32", "f16x3", "f16x3g"):
+        torch.manual_seed(0)
+        tr = TrainStep(GCN_GRU(13, 13, 13, S * 13, H, math=math).to(dev), lr=1e-3)
+        traj[math] = [float(tr.step(A, X, L)[0]) for _ in range(12)]
+        tr.check()
+    assert traj["f32"][-1] < 0.5 * traj["f32"][0]                       # it really trains
+    for i, ref in enumerate(traj["f32"]):
+        for math in ("f16x3", "f16x3g"):
+            assert abs(traj[math][i] / ref - 1.0) <= 2e-5, (i, math, traj[math][i], ref)
+        assert abs(traj["f16x3g"][i] - traj["f16x3"][i]) <= 1e-6 * ref, (i, traj["f16x3g"][i], traj["f16x3"][i])
