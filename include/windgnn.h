@@ -73,8 +73,8 @@ typedef enum wgnn_math {
   WGNN_MATH_F16 = 2,   /* plain fp16 operands, one MFMA pass, fp32 accumulate: ~1e-3 error (16-bit config) */
   WGNN_MATH_F16X3G = 3 /* F16X3, except that from B*T >= 4096 rows the backward's gate gradients (dGI, dGH_n) leave the BPTT
                           kernel as ONE fp16 plane and the three GEMMs they feed run fewer MFMA passes: dW_hh and dg two
-                          (hi x (hi + lo)), dW_ih one (hi x hi).  Forward, recurrences and the GCN backward are F16X3's
-                          (Y identical).  Gradients: every dropped lo half is a relative rounding of 2^-12, independent
+                          (hi x (hi + lo)), dW_ih one (hi x hi); dg itself, too, is written as one fp16 plane (dense
+                          adjacency).  Forward, recurrences and the GCN backward's own chain are F16X3's (Y identical).  Gradients: every dropped lo half is a relative rounding of 2^-12, independent
                           per element, that averages out over the B*T rows a weight gradient sums -- observed <= 9e-6 of
                           the tensor's max against the fp64 oracle at B*T = 6144 with the MSE loss (F16X3: 1.3e-6), and
                           at worst ~4e-4 when dY is pure zero-mean noise (a gradient that is itself a fully cancelling

@@ -28,6 +28,7 @@ struct Layout {
   bool x3, gen_gcn, gen_gru, g32, g32tn;
   int hq;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
+  bool dg16;                                     // ... and dg itself ONE fp16 plane (dense GCN only)
   bool dgi1;                                     // f16x3 at large B*T: dGI / dGHn are ONE fp16 plane, their three GEMMs run two passes
   bool small, rec32;                             // exact fp32: one-window-per-workgroup recurrences / the register-resident MFMA ones
   size_t st_hprev;                               // exact fp32, large B*T: [Hprev | 1 | 0..] rows written by the forward recurrence
@@ -118,6 +119,7 @@ Layout make_layout(const wgnn_dims* d) {
   // element); it averages out in everything they feed -- the weight gradients sum B*T rows, the conv gradients B*T*S -- and
   // the lo plane is not written, staged or multiplied (error model and measured errors)
   L.dgi1 = d->math == WGNN_MATH_F16X3G && !L.gen_gru && L.BT >= 4096;
+  L.dg16 = L.dgi1 && !L.gen_gcn;            // the GCN backward rounds dg to fp16 planes anyway: measured conv gradients 5.0e-6 vs 1.7e-6
   L.hn = x3 ? grux_hn(d->H) : gru_hn(d->H);
   L.msplit = x3 ? grux_msplit(d->H) : gru_msplit(d->H);
   // GEMM rows of the dW_hh product: [dGI_r | dGI_z | pad to msplit | dGHn]
@@ -595,7 +597,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       if (rc != WGNN_OK) return rc;
     }
     rc = launch_pgemm_nt(dGIh, L.gen_gru ? dGIh + PG : dGIlo, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.Id,
-                         (int)L.I, nullptr, full, nullptr, st);
+                         (int)L.I, nullptr, full, nullptr, st, L.dg16);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gcn) {
       rc = launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
@@ -603,7 +605,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       if (rc != WGNN_OK || defer) return rc;
       return reduce_now(2);
     }
-    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, Xv, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg, (int)L.Id,
+    rc = launch_gcnx2_bwd((int)L.BT, d->S, A, Xv, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, gact, (int)L.Ip, dg, (int)L.Id, L.dg16,
                           scales, /*scale_in=*/0, ws + L.ws_gcnpart, full, ws + L.ws_xtail_b, st);
     if (rc != WGNN_OK || defer) return rc;
     return reduce_now(2);

@@ -151,8 +151,9 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io /*
                      const float* W2, const float* b2, void* g_planes, int ldg, bool x3, unsigned* status, void* xtail_scratch,
                      hipStream_t st);   // xtail_scratch: >= S*13 + 1 elements of workspace when S*13 is odd
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
-                     const float* W2, const void* g_planes, int ldg, const float* dg, int ld_dg /*row pitch of dg*/,
-                     const float* scales, int scale_in, float* partial, bool x3, void* xtail_scratch, hipStream_t st);
+                     const float* W2, const void* g_planes, int ldg, const void* dg, int ld_dg /*row pitch of dg, elements*/,
+                     bool dg16 /*dg is one fp16 plane (x3 only)*/, const float* scales, int scale_in, float* partial, bool x3,
+                     void* xtail_scratch, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
                          int Rp, int Cp, unsigned* status, hipStream_t st);
@@ -161,8 +162,9 @@ int pgemm_tn_tiles(int Mout, int Nout);   // output tiles per K chunk (sizes the
 size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk);
 // kpart (nullable): pgemm_nt_kpart_floats(M, ldc, Kp) floats of split-K scratch for few-row, long-K products
 size_t pgemm_nt_kpart_floats(int M, int ldc, int Kp);
+// out16: C is ONE fp16 plane with row pitch ldc halfs (x3 with a single-plane A operand only)
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                    int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st);
+                    int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st, bool out16 = false);
 // A2hi != null: columns m >= msplit of the A operand are column m - msplit of the planes A2hi / A2lo (row stride lda2)
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
                     int K, int splitk, float* partial, int Mout, int Nout, bool x3, const void* A2hi, const void* A2lo,

@@ -465,15 +465,18 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 // registers (268 vs 136 us) and stays at 12 waves.
 constexpr int bwd_waves(int NT, bool X3) { return (!X3 && NT <= 3) ? 16 : 12; }
 
-template <int NT, bool X3, bool IO>
+// DG16: dg arrives as ONE fp16 plane (pgemm_nt_kernel<.., OUT16>, WGNN_MATH_F16X3G) instead of fp32
+template <int NT, bool X3, bool IO, bool DG16>
 __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const void* __restrict__ X, const void* __restrict__ xtail, int io,
                                                        const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const _Float16* __restrict__ gact, int ld_g,
-                                                       const float* __restrict__ dg, int ld_dg,
+                                                       const void* __restrict__ dgv, int ld_dg,
                                                        const float* __restrict__ scales, int scale_in,
                                                        float* __restrict__ partial) {
+  const float* dg = (const float*)dgv;
+  const _Float16* dgh = (const _Float16*)dgv;
   constexpr int KS = (NT + 1) / 2;
   constexpr int NF = NT * KS;
   constexpr int SP = 16 * NT;
@@ -547,12 +550,13 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
   f32x4 dW1acc = zero4, dW2acc = zero4, dW1acc16 = zero4, dW2acc16 = zero4;   // K = 32 / K = 16 steps (MIXED_FORMS)
   float db1acc = 0.f, db2acc = 0.f;
 
-  f32x2 xr[NP], dr[NP];
-  h2 gr[NP];
+  f32x2 xr[NP], dr[DG16 ? 1 : NP];
+  h2 gr[NP], drh[DG16 ? NP : 1];
   if (wave_id < ntiles) {
     XLOAD(wave_id);
     gload_pairs_h<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
-    gload_pairs<NP>(dr, dg + (size_t)wave_id * ld_dg, lane, I);
+    if constexpr (DG16) gload_pairs_h<NP>(drh, dgh + (size_t)wave_id * ld_dg, lane, I);
+    else gload_pairs<NP>(dr, dg + (size_t)wave_id * ld_dg, lane, I);
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     asm volatile("" ::: "memory");   // keep the A / A^T fragment reads in LDS (no hoisting into 96 VGPRs)
@@ -563,8 +567,10 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
         const f32x2 xv = IO ? io_pair(xr[k], io) : xr[k];
         xb[map.o0[k]] = xv[0];
         xb[map.o1[k]] = xv[1];
-        db[map.o0[k]] = (float)gr[k][0] > 0.f ? dr[k][0] * s_in : 0.f;     // dZ2 = dg * (g > 0), range-scaled
-        db[map.o1[k]] = (float)gr[k][1] > 0.f ? dr[k][1] * s_in : 0.f;
+        const float d0 = DG16 ? (float)drh[DG16 ? k : 0][0] : dr[DG16 ? 0 : k][0];
+        const float d1 = DG16 ? (float)drh[DG16 ? k : 0][1] : dr[DG16 ? 0 : k][1];
+        db[map.o0[k]] = (float)gr[k][0] > 0.f ? d0 * s_in : 0.f;           // dZ2 = dg * (g > 0), range-scaled
+        db[map.o1[k]] = (float)gr[k][1] > 0.f ? d1 * s_in : 0.f;
       }
     }
     wave_lds_fence();
@@ -572,7 +578,8 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
       const size_t nt = (size_t)(tile + nwaves);
       XLOAD(tile + nwaves);
       gload_pairs_h<NP>(gr, gact + nt * ld_g, lane, I);
-      gload_pairs<NP>(dr, dg + nt * ld_dg, lane, I);
+      if constexpr (DG16) gload_pairs_h<NP>(drh, dgh + nt * ld_dg, lane, I);
+      else gload_pairs<NP>(dr, dg + nt * ld_dg, lane, I);
     }
     // ---- recompute U1, H1 [s][f]
     f32x4 U[NT];
@@ -776,26 +783,28 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, c
 }
 
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
-                     const float* W2, const void* g_planes, int ldg, const float* dg, int ld_dg, const float* scales,
+                     const float* W2, const void* g_planes, int ldg, const void* dg, int ld_dg, bool dg16, const float* scales,
                      int scale_in, float* partial, bool x3, void* xtail_scratch, hipStream_t st) {
-  if (ld_dg < S * 13 || (ld_dg & 1)) return WGNN_ERR_SHAPE;      // rows of dg: 8-byte aligned pairs
+  if (ld_dg < S * 13 || (ld_dg & 1) || (dg16 && !x3)) return WGNN_ERR_SHAPE;      // rows of dg: aligned pairs
   int rc0;
   const void* xt = xtail_copy(X, ntiles, S, io, xtail_scratch, st, &rc0);
   if (rc0 != WGNN_OK) return rc0;
   const _Float16* g = (const _Float16*)g_planes;   // hi plane carries the sign: g > 0 <=> hi > 0
   const double fl = (double)ntiles * ((2.0 * S * S * 13 + 2.0 * S * 13 * 13) * 3.0 + 2.0 * S * 13 * 13 * 2.0);
   // what the launch reads: X and dg as fp32, and the fp16 hi plane of g (2 bytes x ldg per tile) as the ReLU mask
-  const double by = (double)ntiles * (S * 13 * (io ? 2.0 : 4.0) + S * 13 * 4.0 + ldg * 2.0);
+  const double by = (double)ntiles * (S * 13 * (io ? 2.0 : 4.0) + S * 13 * (dg16 ? 2.0 : 4.0) + ldg * 2.0);
   const dim3 grid(grid_x(ntiles, S, x3));
-#define BWD_LAUNCH(NT, X3V, IOV, NAME)                                                                            \
+#define BWD_LAUNCH(NT, X3V, IOV, D16, NAME)                                                                       \
   PROF_LAUNCH(NAME, fl, by, st,                                                                                   \
-              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV>), grid, dim3(64 * bwd_waves(NT, X3V)), 0, st, ntiles, S, A, X, xt, io, \
+              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV, D16>), grid, dim3(64 * bwd_waves(NT, X3V)), 0, st, ntiles, S, A, X, xt, io, \
                                  W1, b1, W2, g, ldg, dg, ld_dg, scales, scale_in, partial))
 #define BWD_CASE(NT)                                                                                              \
-  if (x3 && !io) BWD_LAUNCH(NT, true, false, "gcnx_bwd_kernel<" #NT ">");                                         \
-  else if (x3) BWD_LAUNCH(NT, true, true, "gcnx_bwd_kernel<" #NT ">");                                            \
-  else if (!io) BWD_LAUNCH(NT, false, false, "gcnx_bwd_kernel<" #NT ",f16>");                                     \
-  else BWD_LAUNCH(NT, false, true, "gcnx_bwd_kernel<" #NT ",f16>")
+  if (x3 && dg16 && !io) BWD_LAUNCH(NT, true, false, true, "gcnx_bwd_kernel<" #NT ">");                           \
+  else if (x3 && dg16) BWD_LAUNCH(NT, true, true, true, "gcnx_bwd_kernel<" #NT ">");                              \
+  else if (x3 && !io) BWD_LAUNCH(NT, true, false, false, "gcnx_bwd_kernel<" #NT ">");                             \
+  else if (x3) BWD_LAUNCH(NT, true, true, false, "gcnx_bwd_kernel<" #NT ">");                                     \
+  else if (!io) BWD_LAUNCH(NT, false, false, false, "gcnx_bwd_kernel<" #NT ",f16>");                              \
+  else BWD_LAUNCH(NT, false, true, false, "gcnx_bwd_kernel<" #NT ",f16>")
   switch ((S + 15) / 16) {
     case 1: BWD_CASE(1); break;
     case 2: BWD_CASE(2); break;

@@ -42,7 +42,11 @@ __device__ __forceinline__ f32x4 mfma_q(h8 a, h8 b, f32x4 c) {
 
 // ALO (with X3): the A operand has a lo plane (three passes lo*hi + hi*lo + hi*hi); false: A is a single fp16 plane and
 // the product is hi*lo + hi*hi (two passes, no A-lo staging) -- the backward's dGI at large B*T, see DESIGN.md section 3.
-template <int T, bool X3, bool ALO>
+// OUT16: C is a single fp16 plane (row pitch ldc in halfs): an accumulator quad's value is exchanged with the neighbouring
+// lane (DPP quad_perm [1,0,3,2]) so that every lane stores two packed (column, column + 1) pairs -- 32-byte segments per 16
+// lanes, half the bytes of the fp32 epilogue.  Used for dg in WGNN_MATH_F16X3G (its consumer, the GCN backward, rounds dg to
+// fp16 planes anyway; the single plane's rounding averages out in the conv gradients' sums over B*T*S rows).
+template <int T, bool X3, bool ALO, bool OUT16>
 __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16* __restrict__ Ahi,
                                                                 const _Float16* __restrict__ Alo, int lda, int M,
                                                                 int Kp, const _Float16* __restrict__ Bpl, int Np,
@@ -172,6 +176,35 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     compute(smem + (kt & 1) * STAGE);
   }
 
+  if (OUT16) {
+    _Float16* Ch = (_Float16*)C;
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      const int col = n0 + BNW * wn + 16 * j + r16, colp = col & ~1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x4 v = acc[i][j] * s_out;
+        // even lanes keep rows 0, 1 of the quad and take the partner's values of the same rows (column + 1);
+        // odd lanes keep rows 2, 3 and take the partner's (column - 1)
+        const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];            // what the partner needs from me
+        const float k0 = odd ? v[2] : v[0], k1 = odd ? v[3] : v[1];            // what I keep
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        const f2v a0 = {odd ? r0 : k0, odd ? k0 : r0}, a1 = {odd ? r1 : k1, odd ? k1 : r1};
+        const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a0, h2v));
+        const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(a1, h2v));
+        const int row = m0 + 32 * wm + 16 * i + 4 * c4 + (odd ? 2 : 0);
+        if (colp < N) {
+          if (row < M) *(unsigned*)(Ch + (size_t)row * ldc + colp) = p0;
+          if (row + 1 < M) *(unsigned*)(Ch + (size_t)(row + 1) * ldc + colp) = p1;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < T; ++j) {
     const int col = n0 + BNW * wn + 16 * j + r16;
@@ -436,15 +469,16 @@ int pgemm_nt_np(int N) { return cdiv_i(N, 32) * 32 + 448 - 32; }
 
 template <int T>
 static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                       int ldc, int N, const float* s_out, bool x3, int nsl, float* kpart, hipStream_t st) {
+                       int ldc, int N, const float* s_out, bool x3, int nsl, float* kpart, bool out16, hipStream_t st) {
   const bool alo = Alo != nullptr;                 // x3 with a single-plane A operand: two passes
   const int nm = cdiv_i(M, NT_BM);
   const int grid = (nm >= 8 ? cdiv_i(nm, 8) * 8 : nm) * nsl;
   const size_t smem = 2 * (size_t)(2 * NT_BM + 2 * 32 * T) * 64;
-  static std::atomic<unsigned long long> done{0}, done16{0}, done2{0};
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, true>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false>, smem, done2) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
+  static std::atomic<unsigned long long> done{0}, done16{0}, done2{0}, done2h{0};
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, true, false>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false, false>, smem, done2) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false, true>, smem, done2h) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
   static const std::string name = "pgemm_nt_kernel<" + std::to_string(T) + ">", name16 = "pgemm_nt_kernel<" + std::to_string(T) + ",f16>",
                            name2 = "pgemm_nt_kernel<" + std::to_string(T) + ",x2>";
   // Long contractions (the 4096-station projections: K = 53 248) run as 2048-wide K chunks: an fp32 accumulator
@@ -454,6 +488,7 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
   const size_t bplane = (size_t)Np * Kp;
   const bool split = kpart && nchunks > 1;
   const int nlaunch = split ? 1 : nchunks;
+  if (out16 && (!x3 || alo || nchunks > 1 || (ldc & 1))) return WGNN_ERR_UNSUPPORTED;   // fp16 C: the x2 instance, one K chunk
   for (int c = 0; c < nlaunch; ++c) {
     const dim3 g(grid, split ? nchunks : 1);
     float* out = split ? kpart : C;
@@ -461,20 +496,25 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
     const double kk = split ? Kp : (Kp - c * kc_len < kc_len ? Kp - c * kc_len : kc_len);
     const double fl = 2.0 * M * (double)N * kk;
     const double by = (x3 && alo ? 4.0 : 2.0) * (double)M * kk + (x3 ? 4.0 : 2.0) * (double)Np * kk +
-                      4.0 * (double)M * N * (split ? nchunks : (c > 0 ? 2 : 1));
+                      (out16 ? 2.0 : 4.0) * (double)M * N * (split ? nchunks : (c > 0 ? 2 : 1));
     if (x3 && alo)
       PROF_LAUNCH(name.c_str(), fl, by, st,
-                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true, true, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
                                      nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
+    else if (x3 && out16)
+      PROF_LAUNCH(name2.c_str(), fl, by, st,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true, false, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                                     (const _Float16*)Ahi, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
+                                     nm, nsl, bplane, kc_len, c, cstride, 0));
     else if (x3)
       PROF_LAUNCH(name2.c_str(), fl, by, st,
-                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, true, false, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Ahi, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
                                      nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
     else
       PROF_LAUNCH(name16.c_str(), fl, by, st,
-                  hipLaunchKernelGGL((pgemm_nt_kernel<T, false, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, false, true, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Alo, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
                                      nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
     WGNN_CHECK_LAUNCH();
@@ -492,13 +532,13 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
 
 // C[M][N] = s_out * A B^T.  A planes [M][lda] (Kp <= lda), B stage-major planes with Np = pgemm_nt_np(N) rows.
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                    int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st) {
+                    int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st, bool out16) {
   int nsl, T;
   nt_shape(M, N, Kp, kpart != nullptr, nsl, T);
   if (Kp % 32 != 0 || lda % 8 != 0 || Np < nsl * 32 * T) return WGNN_ERR_SHAPE;
   switch (T) {
 #define NT_CASE(t) \
-  case t: return launch_nt_t<t>(Ahi, Alo, lda, M, Kp, Bplanes, Np, C, ldc, N, s_out, x3, nsl, kpart, st);
+  case t: return launch_nt_t<t>(Ahi, Alo, lda, M, Kp, Bplanes, Np, C, ldc, N, s_out, x3, nsl, kpart, out16, st);
     NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5) NT_CASE(6) NT_CASE(7) NT_CASE(8) NT_CASE(9) NT_CASE(10)
     NT_CASE(11) NT_CASE(12) NT_CASE(13) NT_CASE(14)
 #undef NT_CASE
