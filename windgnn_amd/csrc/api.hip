@@ -119,7 +119,9 @@ Layout make_layout(const wgnn_dims* d) {
   // element); it averages out in everything they feed -- the weight gradients sum B*T rows, the conv gradients B*T*S -- and
   // the lo plane is not written, staged or multiplied (error model and measured errors)
   L.dgi1 = d->math == WGNN_MATH_F16X3G && !L.gen_gru && L.BT >= 4096;
-  L.dg16 = L.dgi1 && !L.gen_gcn;            // the GCN backward rounds dg to fp16 planes anyway: measured conv gradients 5.0e-6 vs 1.7e-6
+  // (the GCN backward rounds dg to fp16 planes anyway: measured conv gradients 5.0e-6 vs 1.7e-6 in f16x3g; the one-pass
+  // fp16 mode, whose own tolerance is 5e-2, takes it at every size)
+  L.dg16 = (L.dgi1 || (d->math == WGNN_MATH_F16 && !L.gen_gru)) && !L.gen_gcn;
   L.hn = x3 ? grux_hn(d->H) : gru_hn(d->H);
   L.msplit = x3 ? grux_msplit(d->H) : gru_msplit(d->H);
   // GEMM rows of the dW_hh product: [dGI_r | dGI_z | pad to msplit | dGHn]

@@ -152,7 +152,7 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io /*
                      hipStream_t st);   // xtail_scratch: >= S*13 + 1 elements of workspace when S*13 is odd
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const void* dg, int ld_dg /*row pitch of dg, elements*/,
-                     bool dg16 /*dg is one fp16 plane (x3 only)*/, const float* scales, int scale_in, float* partial, bool x3,
+                     bool dg16 /*dg is one fp16 plane*/, const float* scales, int scale_in, float* partial, bool x3,
                      void* xtail_scratch, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
@@ -162,7 +162,7 @@ int pgemm_tn_tiles(int Mout, int Nout);   // output tiles per K chunk (sizes the
 size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk);
 // kpart (nullable): pgemm_nt_kpart_floats(M, ldc, Kp) floats of split-K scratch for few-row, long-K products
 size_t pgemm_nt_kpart_floats(int M, int ldc, int Kp);
-// out16: C is ONE fp16 plane with row pitch ldc halfs (x3 with a single-plane A operand only)
+// out16: C is ONE fp16 plane with row pitch ldc halfs (single-plane A operand only: the x2 and f16 instances)
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
                     int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st, bool out16 = false);
 // A2hi != null: columns m >= msplit of the A operand are column m - msplit of the planes A2hi / A2lo (row stride lda2)

@@ -785,7 +785,7 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, c
 int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const void* g_planes, int ldg, const void* dg, int ld_dg, bool dg16, const float* scales,
                      int scale_in, float* partial, bool x3, void* xtail_scratch, hipStream_t st) {
-  if (ld_dg < S * 13 || (ld_dg & 1) || (dg16 && !x3)) return WGNN_ERR_SHAPE;      // rows of dg: aligned pairs
+  if (ld_dg < S * 13 || (ld_dg & 1)) return WGNN_ERR_SHAPE;      // rows of dg: aligned pairs
   int rc0;
   const void* xt = xtail_copy(X, ntiles, S, io, xtail_scratch, st, &rc0);
   if (rc0 != WGNN_OK) return rc0;
@@ -803,6 +803,8 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
   else if (x3 && dg16) BWD_LAUNCH(NT, true, true, true, "gcnx_bwd_kernel<" #NT ">");                              \
   else if (x3 && !io) BWD_LAUNCH(NT, true, false, false, "gcnx_bwd_kernel<" #NT ">");                             \
   else if (x3) BWD_LAUNCH(NT, true, true, false, "gcnx_bwd_kernel<" #NT ">");                                     \
+  else if (dg16 && !io) BWD_LAUNCH(NT, false, false, true, "gcnx_bwd_kernel<" #NT ",f16>");                       \
+  else if (dg16) BWD_LAUNCH(NT, false, true, true, "gcnx_bwd_kernel<" #NT ",f16>");                               \
   else if (!io) BWD_LAUNCH(NT, false, false, false, "gcnx_bwd_kernel<" #NT ",f16>");                              \
   else BWD_LAUNCH(NT, false, true, false, "gcnx_bwd_kernel<" #NT ",f16>")
   switch ((S + 15) / 16) {

@@ -474,7 +474,8 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
   const int nm = cdiv_i(M, NT_BM);
   const int grid = (nm >= 8 ? cdiv_i(nm, 8) * 8 : nm) * nsl;
   const size_t smem = 2 * (size_t)(2 * NT_BM + 2 * 32 * T) * 64;
-  static std::atomic<unsigned long long> done{0}, done16{0}, done2{0}, done2h{0};
+  static std::atomic<unsigned long long> done{0}, done16{0}, done2{0}, done2h{0}, done16h{0};
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true, true>, smem, done16h) != WGNN_OK) return WGNN_ERR_HIP;
   if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, true, false>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
   if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false, false>, smem, done2) != WGNN_OK) return WGNN_ERR_HIP;
   if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false, true>, smem, done2h) != WGNN_OK) return WGNN_ERR_HIP;
@@ -488,7 +489,7 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
   const size_t bplane = (size_t)Np * Kp;
   const bool split = kpart && nchunks > 1;
   const int nlaunch = split ? 1 : nchunks;
-  if (out16 && (!x3 || alo || nchunks > 1 || (ldc & 1))) return WGNN_ERR_UNSUPPORTED;   // fp16 C: the x2 instance, one K chunk
+  if (out16 && ((x3 && alo) || nchunks > 1 || (ldc & 1))) return WGNN_ERR_UNSUPPORTED;   // fp16 C: the x2 / f16 instances, one K chunk
   for (int c = 0; c < nlaunch; ++c) {
     const dim3 g(grid, split ? nchunks : 1);
     float* out = split ? kpart : C;
@@ -512,6 +513,11 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
                   hipLaunchKernelGGL((pgemm_nt_kernel<T, true, false, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
                                      (const _Float16*)Ahi, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
                                      nm, nsl, bplane, kc_len, c, cstride, c > 0 ? 1 : 0));
+    else if (out16)
+      PROF_LAUNCH(name16.c_str(), fl, by, st,
+                  hipLaunchKernelGGL((pgemm_nt_kernel<T, false, true, true>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
+                                     (const _Float16*)Ahi, lda, M, Kp, (const _Float16*)Bplanes, Np, out, ldc, N, s_out,
+                                     nm, nsl, bplane, kc_len, c, cstride, 0));
     else
       PROF_LAUNCH(name16.c_str(), fl, by, st,
                   hipLaunchKernelGGL((pgemm_nt_kernel<T, false, true, false>), g, dim3(64 * NT_WAVES), smem, st, (const _Float16*)Ahi,
