@@ -25,8 +25,10 @@ def short(n):
             flags = re.findall(r"Lb(\d)E", t.group(1))        # first bool = X3 (false: bench.py prints ",f16"); later
             if flags and flags[0] == "0":                       # flags (e.g. the TN GEMM's two-source A) are not printed
                 args.append("f16")
-            elif name.startswith("pgemm_") and len(flags) >= 2 and flags[-1] == "0":
-                args.append("x2")                               # last bool = ALO (false: single-plane A operand, two passes)
+            elif name.startswith("pgemm_nt") and len(flags) >= 2 and flags[1] == "0":
+                args.append("x2")                               # <T, X3, ALO, OUT16>: ALO false = single-plane A operand, two passes
+            elif name.startswith("pgemm_tn") and len(flags) >= 3 and flags[2] == "0":
+                args.append("x2")                               # <T, X3, A2, ALO>
             return name + ("<" + ",".join(args) + ">" if args else "")
         return name
     n = n.split("(")[0]
