@@ -355,6 +355,10 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": trb,
                         "avg_launch_us": round(avg_s * 1e6, 2)}
         roofline["algorithmic_bytes_per_launch"] = round(d["bytes"] / d["launches"])
+        if d["name"].startswith("gcnx_bwd"):
+            roofline["note"] = ("bound by its chain of dependent per-tile products, not by HBM or issue (DESIGN.md 5, round-3 "
+                                "results); in f16x3g / f16 its dg operand is one fp16 plane, so the launch has 349 MB to move "
+                                "instead of 436 MB: frac fell from 0.37-0.39 (round 2) while the kernel got faster")
         roofline["traffic_source"] = traffic_src
         if trb:
             roofline["traffic_vs_algorithmic"] = round(trb / (d["bytes"] / d["launches"]), 3)
