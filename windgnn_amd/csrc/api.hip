@@ -29,6 +29,7 @@ struct Layout {
   int hq;
   int np_h;                                      // padded rows of split(W_hh^T) (general f16x3 GRU)
   bool dg16;                                     // ... and dg itself ONE fp16 plane (dense GCN only)
+  bool gi16;                                     // one-pass fp16 mode: the input projection GI is ONE fp16 plane
   bool dgi1;                                     // f16x3 at large B*T: dGI / dGHn are ONE fp16 plane, their three GEMMs run two passes
   bool small, rec32;                             // exact fp32: one-window-per-workgroup recurrences / the register-resident MFMA ones
   size_t st_hprev;                               // exact fp32, large B*T: [Hprev | 1 | 0..] rows written by the forward recurrence
@@ -122,6 +123,9 @@ Layout make_layout(const wgnn_dims* d) {
   // (the GCN backward rounds dg to fp16 planes anyway: measured conv gradients 5.0e-6 vs 1.7e-6 in f16x3g; the one-pass
   // fp16 mode, whose own tolerance is 5e-2, takes it at every size)
   L.dg16 = (L.dgi1 || (d->math == WGNN_MATH_F16 && !L.gen_gru)) && !L.gen_gcn;
+  // the one-pass fp16 mode (tolerance class 5e-2) also takes the forward's largest intermediate, GI [B*T][3H], as one fp16
+  // plane: the projection GEMM writes and the recurrence reads half the bytes (rows keep the pitch Gp, in halfs)
+  L.gi16 = d->math == WGNN_MATH_F16 && !L.gen_gru;   // (grux_fwd_kernel<.., X3 = false> reads fp16 rows)
   L.hn = x3 ? grux_hn(d->H) : gru_hn(d->H);
   L.msplit = x3 ? grux_msplit(d->H) : gru_msplit(d->H);
   // GEMM rows of the dW_hh product: [dGI_r | dGI_z | pad to msplit | dGHn]
@@ -315,7 +319,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, img_f, L.np_g3, GI,
-                         (int)L.Gp, (int)L.G3, nullptr, full, nullptr, st);
+                         (int)L.Gp, (int)L.G3, nullptr, full, nullptr, st, L.gi16);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gru) {  // any hidden width: one plane GEMM per step against split(W_hh | b_hh)
       rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 0, p->b_hh, (int)L.H, ws + L.ws_hhp_f, L.np_g3, (int)L.Hp,

@@ -116,7 +116,7 @@ int launch_amax_scale(const float* x, int64_t n, float* scales, float* part /*>=
 bool grux_shape_supported(int H);
 int grux_hp(int H);   // row width (halfs) of the Y planes: 32*ceil((H+1)/32)
 size_t grux_gates_floats(int B, int T, int H, int io);   // gate stash of the register-resident recurrences (their own layout)
-int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, void* Y,
+int launch_grux_fwd(int B, int T, int H, const void* GI /*fp32 rows if x3, else fp16 rows*/, int ldgi, const float* Whh, const float* bhh, void* Y,
                     float* gates, void* y_planes, bool x3, unsigned* status, const void* labels, float* stat_part,
                     int io /*wgnn_io of Y and labels*/, int last_only, float y_mul, float y_add, hipStream_t st);
 int grux_blocks(int B);   // workgroups of launch_grux_fwd = MSE partial pairs it writes when given labels

@@ -12,6 +12,7 @@
 // Backward values (dY ~ 1e-9) are multiplied by the power of two scales[0] on load and written
 // SCALED to dGI/dGH; the weight-gradient GEMMs un-scale in their epilogues.
 #include "common.h"
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -90,8 +91,10 @@ __device__ __forceinline__ void put_split(_Float16* hi, _Float16* lo, int idx, f
 // ------------------------------------------------------------------------------------------------
 // IO: Y and the labels are 16-bit on the wire (fp16 / bf16 by `io`) and move through LDS as whole rows; the fp32
 // instance keeps the direct per-lane accesses (the row path was 30 % slower there: measured 116 vs 84 us).
+// GI: the input projection [B*T][ldgi] in the 3H layout -- fp32 for the split (X3) instances, ONE fp16 plane for the one-pass
+// fp16 instances (WGNN_MATH_F16: pgemm_nt's OUT16 epilogue; half the bytes of the largest intermediate of that mode)
 template <int KS, bool X3, bool IO>   // K steps of 32 over the hidden index (+ the ones column): KS = ceil((H+1)/32)
-__global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const float* __restrict__ GI, int ldgi,
+__global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H, const void* __restrict__ GI, int ldgi,
                                                             const float* __restrict__ Whh,
                                                             const float* __restrict__ bhh, void* __restrict__ Y,
                                                             float* __restrict__ gates, _Float16* __restrict__ yp_hi,
@@ -145,7 +148,8 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
 
   // Addressing: one workgroup-uniform 64-bit base per array (the workgroup's first window) plus 32-bit lane
   // offsets.  Row indices are clamped so every load is unconditional.
-  const float* GIw = GI + (size_t)b0 * T * ldgi;
+  typedef typename std::conditional<X3, float, _Float16>::type gi_t;
+  const gi_t* GIw = (const gi_t*)GI + (size_t)b0 * T * ldgi;
   constexpr int esz = IO ? 2 : 4;                  // bytes per element of Y and the labels (wgnn_io)
   void* Yw = (char*)Y + (size_t)b0 * T * H * esz;
   // gate stash in this kernel's own register layout, [workgroup][t][wave][r | z | n | gh_n][lane] x float4 (the 4 window
@@ -229,9 +233,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = (rowt[r] + tc) * ldgi + jc;
-      dst[0][r] = GIw[o];
-      dst[1][r] = GIw[o + H];
-      dst[2][r] = GIw[o + 2 * H];
+      dst[0][r] = (float)GIw[o];
+      dst[1][r] = (float)GIw[o + H];
+      dst[2][r] = (float)GIw[o + 2 * H];
       if (!IO && Lab) ldst[r] = ((const float*)Labw)[(rowt[r] + tc) * H + jc];
     }
   };
@@ -687,7 +691,7 @@ size_t grux_gates_floats(int B, int T, int H, int io) {
 }
 int grux_blocks(int B) { return cdiv_i(B, MB); }
 
-int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, void* Y,
+int launch_grux_fwd(int B, int T, int H, const void* GI /*fp32 rows (x3) or fp16 rows (one-pass fp16)*/, int ldgi, const float* Whh, const float* bhh, void* Y,
                     float* gates, void* y_planes /*nullable: 2 x [B*T+1][grux_hp(H)] halfs*/, bool x3, unsigned* status,
                     const void* labels /*nullable*/, float* stat_part /*2 * grux_blocks(B) floats if labels*/, int io,
                     int last_only /*Y is [B][H]: only h_{T-1} * y_mul + y_add is written (fp32 I/O, no stash)*/,
@@ -697,7 +701,7 @@ int launch_grux_fwd(int B, int T, int H, const float* GI, int ldgi, const float*
   _Float16* yl = yh ? yh + ((size_t)B * T + 1) * grux_hp(H) : nullptr;   // each plane has B*T + 1 rows
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H,
-               by = bt * (4.0 * 3 * H + (io ? 2.0 : 4.0) * ((last_only ? 0 : H) + (labels ? H : 0))) +
+               by = bt * ((x3 ? 4.0 : 2.0) * 3 * H + (io ? 2.0 : 4.0) * ((last_only ? 0 : H) + (labels ? H : 0))) +
                     (gates ? 4.0 * grux_gates_floats(B, T, H, io) : 0.0);
   const dim3 grid(cdiv_i(B, MB));
 #define FLAUNCH(K, X3V, IOV, NAME)                                                                                 \
