@@ -40,6 +40,19 @@ __device__ __forceinline__ f32x4 mfma_q(h8 a, h8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// Slots of the A ring and the kernel's dynamic LDS.  A third A slot (an A stage then has two compute phases to arrive) pays
+// only in the one-pass instances, whose compute phase is a third as long: pgemm_nt<10,f16> 46.0 -> 42.7 us, <14,f16> 52.2 ->
+// 50.0; the split instances fit it too (T <= 10 with a lo plane of A) and measured 88.2 -> 90.3 / 67.1 -> 65.4 us (<10> / <14,x2>):
+// not what they wait for, so they keep two
+constexpr int nt_a_slot(bool x3, bool alo) { return ((x3 && alo) ? 2 : 1) * NT_BM * 64; }
+constexpr int nt_b_slot(int T, bool x3) { return (x3 ? 2 : 1) * 32 * T * 64; }
+constexpr int nt_a_depth(int T, bool x3, bool alo) {
+  return (!x3 && 3 * nt_a_slot(x3, alo) + 2 * nt_b_slot(T, x3) <= 156 * 1024) ? 3 : 2;
+}
+constexpr size_t nt_smem(int T, bool x3, bool alo) {
+  return (size_t)nt_a_depth(T, x3, alo) * nt_a_slot(x3, alo) + 2 * (size_t)nt_b_slot(T, x3);
+}
+
 // ALO (with X3): the A operand has a lo plane (three passes lo*hi + hi*lo + hi*hi); false: A is a single fp16 plane and
 // the product is hi*lo + hi*hi (two passes, no A-lo staging) -- the backward's dGI at large B*T, see DESIGN.md section 3.
 // OUT16: C is a single fp16 plane (row pitch ldc in halfs): an accumulator quad's value is exchanged with the neighbouring
@@ -65,11 +78,15 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     Kp = min(kc_len, Kp - k0);
   }
   constexpr int BM = NT_BM, BNW = 16 * T, BN = 2 * BNW;
-  constexpr int A_PL = BM * 64, B_PL = BN * 64, STAGE = 2 * A_PL + 2 * B_PL;
+  constexpr int A_PL = BM * 64, B_PL = BN * 64;
   constexpr int PL = X3 ? 2 : 1;                                   // B planes moved: hi (+ lo)
   constexpr int PLA = (X3 && ALO) ? 2 : 1;                         // A planes moved
   constexpr int AP = BM / 16, BP = BN / 16;                        // 1 KB pieces per plane
-  constexpr int NPIECE = PLA * AP + PL * BP, NIT = (NPIECE + NT_WAVES - 1) / NT_WAVES;
+  static_assert(AP == NT_WAVES, "every wave moves exactly PLA pieces of A per stage (the vmcnt below counts them)");
+  constexpr int NITB = (PL * BP + NT_WAVES - 1) / NT_WAVES;        // B pieces per wave and stage (the last one may be off)
+  // Two rings: B (weights: L2-resident) two slots deep, A (the activation planes: HBM) DA slots deep -- three where LDS
+  // allows, so an A stage has two compute phases to arrive instead of one
+  constexpr int A_SLOT = PLA * A_PL, B_SLOT = PL * B_PL, DA = nt_a_depth(T, X3, ALO);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: LDS-DMA bases go to M0
@@ -100,47 +117,50 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
   // a 1 KB "piece" = 16 tile rows x 64 B; the LDS image is lane-linear, so the swizzle the fragment
   // reads expect is applied to the SOURCE chunk index: LDS (row, pos) <- global chunk pos ^ f(row).
   const int prow = lane >> 2, ppos = lane & 3;
-  const _Float16* src[NIT];
-  int dst[NIT], kadv[NIT];
-  bool on[NIT];
+  const int chunk = 8 * (ppos ^ swz16(prow));
+  const _Float16* srcA[PLA];                                         // wave w moves rows 16 w .. 16 w + 15 of every A plane
+  const _Float16* srcB[NITB];
+  int dstB[NITB];
+  bool onB[NITB];
+  {
+    const int gr = min(m0 + 16 * wave + prow, M - 1);               // rows past M are computed but never stored
+    srcA[0] = Ahi + (size_t)gr * lda + chunk;
+    if (PLA == 2) srcA[PLA - 1] = Alo + (size_t)gr * lda + chunk;
+  }
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int p = wave + NT_WAVES * it;
-    on[it] = p < NPIECE;                                            // wave-uniform
-    const int pp = on[it] ? p : 0;
-    const int chunk = 8 * (ppos ^ swz16(prow));
-    if (pp < PLA * AP) {
-      const int plane = pp / AP, blk = pp % AP;
-      const int gr = min(m0 + 16 * blk + prow, M - 1);            // rows past M are computed but never stored
-      src[it] = (plane ? Alo : Ahi) + (size_t)gr * lda + chunk;
-      dst[it] = plane * A_PL + blk * 1024;
-      kadv[it] = 32;
-    } else {
-      const int q = pp - PLA * AP;
-      const int plane = q / BP, blk = q % BP;
-      src[it] = Bpl + (size_t)plane * bplane + (size_t)(n0 + 16 * blk + prow) * 32 + chunk;
-      dst[it] = 2 * A_PL + plane * B_PL + blk * 1024;
-      kadv[it] = Np * 32;
-    }
+  for (int it = 0; it < NITB; ++it) {
+    const int q = wave + NT_WAVES * it;
+    onB[it] = q < PL * BP;                                          // wave-uniform
+    const int plane = onB[it] ? q / BP : 0, blk = onB[it] ? q % BP : 0;
+    srcB[it] = Bpl + (size_t)plane * bplane + (size_t)(n0 + 16 * blk + prow) * 32 + chunk;
+    dstB[it] = plane * B_PL + blk * 1024;
   }
   const int nk = Kp / 32;
   const int r16 = lane & 15, c4 = lane >> 4;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef __attribute__((address_space(1))) const void glb_void;
+  char* const ringA = smem;
+  char* const ringB = smem + DA * A_SLOT;
 
-  auto dma_stage = [&](char* st, int kt) {
+  auto dma_A = [&](int slot, int kt) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it)
-      if (on[it])
-        __builtin_amdgcn_global_load_lds((glb_void*)(src[it] + (size_t)kadv[it] * kt), (lds_void*)(st + dst[it]), 16, 0,
-                                         0);
+    for (int pl = 0; pl < PLA; ++pl)
+      __builtin_amdgcn_global_load_lds((glb_void*)(srcA[pl] + (size_t)32 * kt),
+                                       (lds_void*)(ringA + slot * A_SLOT + pl * A_PL + wave * 1024), 16, 0, 0);
+  };
+  auto dma_B = [&](int slot, int kt) {
+#pragma unroll
+    for (int it = 0; it < NITB; ++it)
+      if (onB[it])
+        __builtin_amdgcn_global_load_lds((glb_void*)(srcB[it] + (size_t)Np * 32 * kt),
+                                         (lds_void*)(ringB + slot * B_SLOT + dstB[it]), 16, 0, 0);
   };
   const int a_off0 = sw16_off(32 * wm + r16, c4), a_off1 = a_off0 + 16 * 64;
   const int b_off = sw16_off(BNW * wn + r16, c4);
-  auto compute = [&](const char* cur) {
-    const char* Ah = cur;
-    const char* Al = cur + A_PL;
-    const char* Bh = cur + 2 * A_PL + b_off;
+  auto compute = [&](const char* curA, const char* curB) {
+    const char* Ah = curA;
+    const char* Al = curA + A_PL;
+    const char* Bh = curB + b_off;
     const char* Bl = Bh + B_PL;
     h8 ah[2], al[2];
     ah[0] = *(const h8*)(Ah + a_off0);
@@ -167,13 +187,41 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     }
   };
 
-  // Two-stage ring: stage kt+1 is in flight while stage kt is multiplied.
-  dma_stage(smem, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // all waves: stage kt visible, stage kt-1 no longer being read
-    if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kt + 1);
-    compute(smem + (kt & 1) * STAGE);
+  if constexpr (DA == 2) {
+    // Two-stage ring: stage kt+1 is in flight while stage kt is multiplied.
+    dma_A(0, 0);
+    dma_B(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // all waves: stage kt visible, stage kt-1 no longer being read
+      if (kt + 1 < nk) {
+        dma_A((kt + 1) & 1, kt + 1);
+        dma_B((kt + 1) & 1, kt + 1);
+      }
+      compute(ringA + (kt & 1) * A_SLOT, ringB + (kt & 1) * B_SLOT);
+    }
+  } else {
+    // A three slots deep, B two.  Iteration kt issues B(kt+1), THEN A(kt+2): a wave's loads complete in issue order, so
+    // "at most the PLA loads of A(kt+1) still outstanding" (vmcnt(PLA)) at the top of iteration kt means B(kt) and A(kt)
+    // have landed while A(kt+1) is still on its way.  When there is no A(kt+1) (last stage) the wait is for everything.
+    dma_A(0, 0);
+    dma_B(0, 0);
+    if (nk > 1) dma_A(1, 1);
+    int sa = 0;                          // kt % 3
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        if (PLA == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();      // all waves: stage kt visible; nobody still reads stage kt-1 (its slots are reused now)
+      if (kt + 1 < nk) dma_B((kt + 1) & 1, kt + 1);
+      const int sa2 = sa == 0 ? 2 : sa - 1;             // (kt + 2) % 3
+      if (kt + 2 < nk) dma_A(sa2, kt + 2);
+      compute(ringA + sa * A_SLOT, ringB + (kt & 1) * B_SLOT);
+      sa = sa == 2 ? 0 : sa + 1;
+    }
   }
 
   if (OUT16) {
@@ -473,13 +521,14 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
   const bool alo = Alo != nullptr;                 // x3 with a single-plane A operand: two passes
   const int nm = cdiv_i(M, NT_BM);
   const int grid = (nm >= 8 ? cdiv_i(nm, 8) * 8 : nm) * nsl;
-  const size_t smem = 2 * (size_t)(2 * NT_BM + 2 * 32 * T) * 64;
+  constexpr size_t smem3 = nt_smem(T, true, true), smem2 = nt_smem(T, true, false), smem1 = nt_smem(T, false, true);
+  const size_t smem = x3 ? (alo ? smem3 : smem2) : smem1;
   static std::atomic<unsigned long long> done{0}, done16{0}, done2{0}, done2h{0}, done16h{0};
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true, true>, smem, done16h) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, true, false>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false, false>, smem, done2) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false, true>, smem, done2h) != WGNN_OK) return WGNN_ERR_HIP;
-  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true, false>, smem, done16) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true, true>, smem1, done16h) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, true, false>, smem3, done) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false, false>, smem2, done2) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, true, false, true>, smem2, done2h) != WGNN_OK) return WGNN_ERR_HIP;
+  if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true, false>, smem1, done16) != WGNN_OK) return WGNN_ERR_HIP;
   static const std::string name = "pgemm_nt_kernel<" + std::to_string(T) + ">", name16 = "pgemm_nt_kernel<" + std::to_string(T) + ",f16>",
                            name2 = "pgemm_nt_kernel<" + std::to_string(T) + ",x2>";
   // Long contractions (the 4096-station projections: K = 53 248) run as 2048-wide K chunks: an fp32 accumulator
