@@ -355,15 +355,19 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
   const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
 
+  // The staging writes and the copy-out's LDS reads below carry NO per-k guard: pairs past the tile go to / come from the
+  // dump and pad slots, so all of them sit in one basic block and issue back to back.  (With a wave-uniform
+  // `if (64 * k < npairs)` around each pair the compiler emitted one block per k -- two ds_read, s_waitcnt lgkmcnt(0), the
+  // split, two stores -- i.e. five serial LDS round trips per tile in the copy-out.)
   f32x2 xr[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) xr[k] = f32x2{0.f, 0.f};          // a k past the tile is never loaded: defined bits for the dump slot
   auto stage_x = [&]() {
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      if (64 * k < npairs) {       // wave-uniform
-        const f32x2 v = IO ? io_pair(xr[k], io) : xr[k];
-        xb[map.o0[k]] = v[0];
-        xb[map.o1[k]] = v[1];
-      }
+      const f32x2 v = IO ? io_pair(xr[k], io) : xr[k];
+      xb[map.o0[k]] = v[0];
+      xb[map.o1[k]] = v[1];
     }
   };
   if (wave_id < ntiles) {
@@ -429,18 +433,26 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
        // column I carries 1.0 (the ones column that yields b_ih / db_ih in the GEMMs), later pads 0
       unsigned* dh = (unsigned*)(ghi + (size_t)tile * ldp);
       unsigned* dl = (unsigned*)(glo + (size_t)tile * ldp);
+      float v0[NP], v1[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {                               // every read first (omap is valid for every lane and k)
+        v0[k] = ob[omap.o0[k]];                                    // the tile, then 1.0 at column I, then zeros
+        v1[k] = ob[omap.o1[k]];
+      }
+      unsigned hi[NP], lo[NP];
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        if (64 * k < ldp / 2) {
+        float d0, d1;                                              // v - hi: -inf where the value rounded to fp16's inf
+        split2t(v0[k], v1[k], hi[k], lo[k], d0, d1);
+        chk = __builtin_fmaf(d0, 0.f, __builtin_fmaf(d1, 0.f, chk));
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (64 * k < ldp / 2) {                                    // wave-uniform
           const int p = lane + 64 * k;
-          const float v0 = ob[omap.o0[k]], v1 = ob[omap.o1[k]];   // the tile, then 1.0 at column I, then zeros
-          unsigned hi, lo;
-          float d0, d1;                                            // v - hi: -inf where the value rounded to fp16's inf
-          split2t(v0, v1, hi, lo, d0, d1);
-          chk = __builtin_fmaf(d0, 0.f, __builtin_fmaf(d1, 0.f, chk));
           if (p < ldp / 2) {
-            dh[p] = hi;
-            if (X3) dl[p] = lo;
+            dh[p] = hi[k];
+            if (X3) dl[p] = lo[k];
           }
         }
       }
