@@ -19,6 +19,7 @@
 //   g[s][f']   = relu(A U2 + b2), produced as g^T[f'][s] and stored station-major.
 // Backward chain: see gcnx_bwd_kernel.
 #include "common.h"
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
@@ -349,7 +350,6 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
   constexpr int ONES = 16, ZERO = 17;                 // pad words of row 0 (columns 16, 17 of XS = 20): never a store target
   omap.init_out(lane, I, ONES, ZERO);
   if (lane == 0) ob[ONES] = 1.f;                      // ob[ZERO] stays 0 from the clear above
-  const int npairs = (I + 1) / 2;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const f32x4 bias1 = {bb1[0], bb1[1], bb1[2], bb1[3]}, bias2 = {bb2[0], bb2[1], bb2[2], bb2[3]};   // accumulator seeds
   const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -363,11 +363,20 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 #pragma unroll
   for (int k = 0; k < NP; ++k) xr[k] = f32x2{0.f, 0.f};          // a k past the tile is never loaded: defined bits for the dump slot
   auto stage_x = [&]() {
+    if (IO && io == 1) {                                           // one branch on the 16-bit type per tile, not one per pair
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const f32x2 v = IO ? io_pair(xr[k], io) : xr[k];
-      xb[map.o0[k]] = v[0];
-      xb[map.o1[k]] = v[1];
+      for (int k = 0; k < NP; ++k) {
+        const f32x2 v = io_pair(xr[k], 1);
+        xb[map.o0[k]] = v[0];
+        xb[map.o1[k]] = v[1];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const f32x2 v = IO ? io_pair(xr[k], 2) : xr[k];
+        xb[map.o0[k]] = v[0];
+        xb[map.o1[k]] = v[1];
+      }
     }
   };
   if (wave_id < ntiles) {
@@ -554,7 +563,6 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
   const float s_in = (scales && scale_in) ? scales[0] : 1.f, s_out = scales ? scales[1] : 1.f;
   PairMap<NP> map;
   map.init(lane, I, SP * XS - 1);
-  const int npairs = (I + 1) / 2;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -564,6 +572,13 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
 
   f32x2 xr[NP], dr[DG16 ? 1 : NP];
   h2 gr[NP], drh[DG16 ? NP : 1];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {                 // a k past the tile is never loaded: defined bits for the dump slot
+    xr[k] = f32x2{0.f, 0.f};
+    gr[k] = h2{(_Float16)0.f, (_Float16)0.f};
+    if (DG16) drh[DG16 ? k : 0] = h2{(_Float16)0.f, (_Float16)0.f};
+    else dr[DG16 ? 0 : k] = f32x2{0.f, 0.f};
+  }
   if (wave_id < ntiles) {
     XLOAD(wave_id);
     gload_pairs_h<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
@@ -573,10 +588,12 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
     asm volatile("" ::: "memory");   // keep the A / A^T fragment reads in LDS (no hoisting into 96 VGPRs)
     wave_lds_fence();
+    // (no per-k guard: pairs past the tile go to the dump slot, so the 4 NP stores sit in one basic block; one branch on the
+    // 16-bit type per tile)
+    auto stage = [&](auto ioc) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      if (64 * k < npairs) {       // wave-uniform; lanes past the tile write the dump slot
-        const f32x2 xv = IO ? io_pair(xr[k], io) : xr[k];
+      for (int k = 0; k < NP; ++k) {
+        const f32x2 xv = IO ? io_pair(xr[k], decltype(ioc)::value) : xr[k];
         xb[map.o0[k]] = xv[0];
         xb[map.o1[k]] = xv[1];
         const float d0 = DG16 ? (float)drh[DG16 ? k : 0][0] : dr[DG16 ? 0 : k][0];
@@ -584,7 +601,9 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
         db[map.o0[k]] = (float)gr[k][0] > 0.f ? d0 * s_in : 0.f;           // dZ2 = dg * (g > 0), range-scaled
         db[map.o1[k]] = (float)gr[k][1] > 0.f ? d1 * s_in : 0.f;
       }
-    }
+    };
+    if (IO && io == 1) stage(std::integral_constant<int, 1>{});
+    else stage(std::integral_constant<int, 2>{});
     wave_lds_fence();
     if (tile + nwaves < ntiles) {                               // prefetch the next tile under this one's math
       const size_t nt = (size_t)(tile + nwaves);
