@@ -1272,4 +1272,27 @@ def test_f16x3g_training_trajectory_at_full_batch_tracks_exact_fp32_like_strict_
     for i, ref in enumerate(traj["f32"]):
         for math in ("f16x3", "f16x3g"):
             assert abs(traj[math][i] / ref - 1.0) <= 2e-5, (i, math, traj[math][i], ref)
-        assert abs(traj["f16x3g"][i] - traj["f16x3"][i]) <= 1e-6 * ref, (i, traj["f16x3g"][i], traj["f16x3"][i])
+        assert abs(traj["f16x3g"][i] - traj["f16x3"][i]) <= 1e-6 * ref, (i, traj["f16x3g"][i], traj["f16x3"][i])@pytest.mark.gpu
+@pytest.mark.parametrize("S,T,B,H,k", [(300, 2, 3, 60, 8), (34, 6, 5, 102, 4)])
+def test_csr_adjacency_one_pass_fp16_mode(S, T, B, H, k):
+    """WGNN_MATH_F16 with a CSR adjacency and the register-resident recurrence: the input projection leaves the GEMM as ONE
+    fp16 plane (pgemm_nt's packed epilogue) and, at S = 300, as ONE K chunk of 3904 (the split modes would take two) --
+    held to the one-pass mode's own tolerance class."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    dev = _dev()
+    csr = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=S), k))
+    A = csr.dense()
+    g = torch.Generator().manual_seed(177 + S)
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    p = orc.init_params(S, 13, H, seed=S + H)
+    Yo, loss_o, go = _oracle_step(A, X, L, p)
+    model = _model_from(p, S, H, "f16")
+    out, loss, grads = _run_step(model, csr.to(dev), X.to(dev), L.to(dev))
+    assert max_abs(out.reshape(Yo.shape), Yo) <= F16_Y_TOL
+    for key in PARAM_KEYS:
+        assert rel_to_max(grads[key], go[key]) <= F16_G_TOL, key
+
+
+
