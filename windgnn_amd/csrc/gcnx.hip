@@ -320,10 +320,28 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
       }
   }
   __syncthreads();
+  // The half fragments (odd NT: the last k step covers 16 stations, 4 halfs per lane and plane) live in registers for the
+  // whole launch -- 4 VGPRs per row tile -- and only the full ones are re-read from LDS per product: a third of the
+  // fragment bytes (6 of 18 KB per tile at NT = 3) no longer cross the CU's one LDS pipe, which 16 waves share
+  constexpr bool HALF = (NT & 1) != 0;
+  h4v ahh[HALF ? NT : 1], ahl[HALF ? NT : 1];
+  if constexpr (HALF) {
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi) {
+      const h8 hh = sCA[((mi * KS + KS - 1) * 2 + 0) * 64 + lane], hl = sCA[((mi * KS + KS - 1) * 2 + 1) * 64 + lane];
+      ahh[mi] = __builtin_shufflevector(hh, hh, 0, 1, 2, 3);
+      ahl[mi] = __builtin_shufflevector(hl, hl, 0, 1, 2, 3);
+    }
+  }
   auto ldA = [&](int mi, int ks) {
     Frag f;
-    f.hi = sCA[((mi * KS + ks) * 2 + 0) * 64 + lane];
-    f.lo = sCA[((mi * KS + ks) * 2 + 1) * 64 + lane];
+    if (HALF && ks == KS - 1) {      // slots j >= 4 of a half fragment are never multiplied by a non-zero partner
+      f.hi = __builtin_shufflevector(ahh[HALF ? mi : 0], ahh[HALF ? mi : 0], 0, 1, 2, 3, 0, 1, 2, 3);
+      f.lo = __builtin_shufflevector(ahl[HALF ? mi : 0], ahl[HALF ? mi : 0], 0, 1, 2, 3, 0, 1, 2, 3);
+    } else {
+      f.hi = sCA[((mi * KS + ks) * 2 + 0) * 64 + lane];
+      f.lo = sCA[((mi * KS + ks) * 2 + 1) * 64 + lane];
+    }
     return f;
   };
   Frag FW1, FW2;
