@@ -20,7 +20,7 @@ __global__ __launch_bounds__(512, 2) void rows_kernel(int ntiles, int I, int ldp
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wave_id = blockIdx.x * 8 + w, nwaves = gridDim.x * 8;
   float* xb = lds + w * 48 * 20;
-  constexpr bool WIDE = MODE & 1, STAGE = MODE & 2, STORE = MODE & 4, WSTORE = MODE & 8;
+  constexpr bool WIDE = MODE & 1, STAGE = MODE & 2, STORE = MODE & 4, WSTORE = MODE & 8, NTS = MODE & 16, NTL = MODE & 32;
   constexpr int NP = 5, NQ = 3;
   int o[NP][2];
   for (int k = 0; k < NP; ++k) {
@@ -38,11 +38,11 @@ __global__ __launch_bounds__(512, 2) void rows_kernel(int ntiles, int I, int ldp
     if (WIDE) {
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
-        if (64 * k < nquads) { int q = lane + 64 * k; int e = q < I / 4 ? 4 * q : I - 4; r4[slot][k] = *(const f32x4u*)(src + e); }
+        if (64 * k < nquads) { int q = lane + 64 * k; int e = q < I / 4 ? 4 * q : I - 4; r4[slot][k] = NTL ? __builtin_nontemporal_load((const f32x4u*)(src + e)) : *(const f32x4u*)(src + e); }
     } else {
 #pragma unroll
       for (int k = 0; k < NP; ++k)
-        if (64 * k < npairs) { int p = lane + 64 * k; if (p >= npairs) p = npairs - 1; r2[slot][k] = *(const f32x2*)(src + 2 * p); }
+        if (64 * k < npairs) { int p = lane + 64 * k; if (p >= npairs) p = npairs - 1; r2[slot][k] = NTL ? __builtin_nontemporal_load((const f32x2*)(src + 2 * p)) : *(const f32x2*)(src + 2 * p); }
     }
   };
 #pragma unroll
@@ -83,15 +83,15 @@ __global__ __launch_bounds__(512, 2) void rows_kernel(int ntiles, int I, int ldp
           if (lane < ldp / 8) {
             u32x4 a = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
             u32x4 b = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
-            *(u32x4*)(P0 + (size_t)t * (ldp / 2) + 4 * lane) = a;
-            *(u32x4*)(P1 + (size_t)t * (ldp / 2) + 4 * lane) = b;
+            if (NTS) { __builtin_nontemporal_store(a, (u32x4*)(P0 + (size_t)t * (ldp / 2) + 4 * lane)); __builtin_nontemporal_store(b, (u32x4*)(P1 + (size_t)t * (ldp / 2) + 4 * lane)); }
+            else { *(u32x4*)(P0 + (size_t)t * (ldp / 2) + 4 * lane) = a; *(u32x4*)(P1 + (size_t)t * (ldp / 2) + 4 * lane) = b; }
           }
         } else {
 #pragma unroll
           for (int k = 0; k < NP; ++k)
             if (64 * k < ldp / 2) {
               int p = lane + 64 * k;
-              if (p < ldp / 2) { P0[(size_t)t * (ldp / 2) + p] = __float_as_uint(v[2 * k]); P1[(size_t)t * (ldp / 2) + p] = __float_as_uint(v[2 * k + 1]); }
+              if (p < ldp / 2) { if (NTS) { __builtin_nontemporal_store(__float_as_uint(v[2 * k]), &P0[(size_t)t * (ldp / 2) + p]); __builtin_nontemporal_store(__float_as_uint(v[2 * k + 1]), &P1[(size_t)t * (ldp / 2) + p]); } else { P0[(size_t)t * (ldp / 2) + p] = __float_as_uint(v[2 * k]); P1[(size_t)t * (ldp / 2) + p] = __float_as_uint(v[2 * k + 1]); } }
             }
         }
       } else {
@@ -141,10 +141,13 @@ int main() {
   for (g_flush = 0; g_flush < 3; ++g_flush) {
     printf("-- before each timed launch: %s\n", g_flush == 0 ? "nothing (X and P resident in the Infinity Cache)" : g_flush == 1 ? "768 MB memset (dirty lines)" : "768 MB read (clean lines)");
     RUN(1, 0, "read 8B/lane depth1");
-    RUN(2, 1, "read 16B/lane depth2");
+    RUN(1, 32, "read 8B/lane depth1, nt loads");
     RUN(1, 4, "read 8B d1 + store 4B/lane");
-    RUN(1, 6, "read 8B d1 + stage + store 4B");
+    RUN(1, 4 + 16, "read 8B d1 + store 4B/lane, nt stores");
+    RUN(1, 4 + 16 + 32, "read 8B d1 + store 4B/lane, nt both");
     RUN(2, 13, "read 16B d2 + store 16B");
+    RUN(2, 13 + 16, "read 16B d2 + store 16B, nt stores");
+    RUN(2, 13 + 16 + 32, "read 16B d2 + store 16B, nt both");
   }
   return 0;
 }

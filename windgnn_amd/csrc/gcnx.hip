@@ -211,14 +211,19 @@ struct PairMap {
   }
 };
 
-template <int NP>
+// STREAM: the tensor is read once per launch and will not be reused before the cache has turned over (X, the old g plane):
+// non-temporal loads do not allocate in the 256 MB Infinity Cache, so they do not evict -- and wait for the write-back of --
+// the dirty lines the previous kernels left there.  (tools/exp/stream_rows.hip: a 174 MB read behind 768 MB of dirty lines
+// takes 61 us with plain loads and 28 us with nt loads.)  Operands a neighbouring kernel just wrote (dg) stay plain: they hit.
+template <int NP, bool STREAM = false>
 __device__ __forceinline__ void gload_pairs(f32x2 (&r)[NP], const float* __restrict__ src, int lane, int I) {
   const int npairs = (I + 1) / 2;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     if (64 * k < npairs) {                               // wave-uniform
       const int p = lane + 64 * k;
-      r[k] = *(const f32x2*)(src + 2 * (p < npairs ? p : npairs - 1));   // clamped: no exec-mask branches
+      const f32x2* q = (const f32x2*)(src + 2 * (p < npairs ? p : npairs - 1));   // clamped: no exec-mask branches
+      r[k] = STREAM ? __builtin_nontemporal_load(q) : *q;
     }
   }
 }
@@ -235,9 +240,9 @@ __device__ __forceinline__ void gload_pairs(f32x2 (&r)[NP], const float* __restr
 // them at staging time (so the wait for the prefetch stays where it was).  `tile_elems` = element offset of the tile.
 template <int NP>
 __device__ __forceinline__ void gload_pairs_io(f32x2 (&r)[NP], const void* __restrict__ base, size_t tile_elems,
-                                               int lane, int I, int io) {
+                                               int lane, int I, int io) {   // X: always a stream
   if (io == 0) {
-    gload_pairs<NP>(r, (const float*)base + tile_elems, lane, I);
+    gload_pairs<NP, true>(r, (const float*)base + tile_elems, lane, I);
     return;
   }
   const unsigned short* src = (const unsigned short*)base + tile_elems;
@@ -246,7 +251,7 @@ __device__ __forceinline__ void gload_pairs_io(f32x2 (&r)[NP], const void* __res
   for (int k = 0; k < NP; ++k) {
     if (64 * k < npairs) {
       const int p = lane + 64 * k;
-      r[k][0] = __builtin_bit_cast(float, *(const unsigned*)(src + 2 * (p < npairs ? p : npairs - 1)));
+      r[k][0] = __builtin_bit_cast(float, __builtin_nontemporal_load((const unsigned*)(src + 2 * (p < npairs ? p : npairs - 1))));
     }
   }
 }
@@ -262,14 +267,15 @@ __device__ __forceinline__ f32x2 io_pair(f32x2 raw, int io) {
   }
   return v;
 }
-template <int NP>
+template <int NP, bool STREAM = false>
 __device__ __forceinline__ void gload_pairs_h(h2 (&r)[NP], const _Float16* __restrict__ src, int lane, int I) {
   const int npairs = (I + 1) / 2;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     if (64 * k < npairs) {
       const int p = lane + 64 * k;
-      r[k] = *(const h2*)(src + 2 * (p < npairs ? p : npairs - 1));
+      const h2* q = (const h2*)(src + 2 * (p < npairs ? p : npairs - 1));
+      r[k] = STREAM ? __builtin_nontemporal_load(q) : *q;
     }
   }
 }
@@ -599,7 +605,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
   }
   if (wave_id < ntiles) {
     XLOAD(wave_id);
-    gload_pairs_h<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
+    gload_pairs_h<NP, true>(gr, gact + (size_t)wave_id * ld_g, lane, I);
     if constexpr (DG16) gload_pairs_h<NP>(drh, dgh + (size_t)wave_id * ld_dg, lane, I);
     else gload_pairs<NP>(dr, dg + (size_t)wave_id * ld_dg, lane, I);
   }
@@ -626,7 +632,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
     if (tile + nwaves < ntiles) {                               // prefetch the next tile under this one's math
       const size_t nt = (size_t)(tile + nwaves);
       XLOAD(tile + nwaves);
-      gload_pairs_h<NP>(gr, gact + nt * ld_g, lane, I);
+      gload_pairs_h<NP, true>(gr, gact + nt * ld_g, lane, I);
       if constexpr (DG16) gload_pairs_h<NP>(drh, dgh + nt * ld_dg, lane, I);
       else gload_pairs<NP>(dr, dg + nt * ld_dg, lane, I);
     }
