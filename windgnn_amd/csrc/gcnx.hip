@@ -214,7 +214,10 @@ struct PairMap {
 // STREAM: the tensor is read once per launch and will not be reused before the cache has turned over (X, the old g plane):
 // non-temporal loads do not allocate in the 256 MB Infinity Cache, so they do not evict -- and wait for the write-back of --
 // the dirty lines the previous kernels left there.  (tools/exp/stream_rows.hip: a 174 MB read behind 768 MB of dirty lines
-// takes 61 us with plain loads and 28 us with nt loads.)  Operands a neighbouring kernel just wrote (dg) stay plain: they hit.
+// takes 61 us with plain loads and 28 us with nt loads.)  Only for whole-line, read-once streams of OLD data: operands a
+// neighbouring kernel has just written (dg here, GI and the gate stash in the recurrences) are still in the cache as dirty
+// lines and a non-temporal load of those is slow (grux_fwd 88 -> 101 us with nt GI loads), and streams read in 64-byte
+// pieces by several instructions (the recurrences' labels) lose their L2 reuse (87 -> 90.5 us): both measured, both plain.
 template <int NP, bool STREAM = false>
 __device__ __forceinline__ void gload_pairs(f32x2 (&r)[NP], const float* __restrict__ src, int lane, int I) {
   const int npairs = (I + 1) / 2;
