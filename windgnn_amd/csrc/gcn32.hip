@@ -21,7 +21,7 @@
 namespace {
 #define LIVE(i, r) ((i) < NT - 1 || (r) < rl)
 // X of tile t; the tensor's last tile comes from the launcher's private copy when S*13 is odd (gcnx.hip, XLOAD)
-#define XLOAD(t) gload_pairs<NP>(xr, (xtail != nullptr && (t) == ntiles - 1) ? xtail : X + (size_t)(t) * I, lane, I)
+#define XLOAD(t) gload_pairs<NP, true>(xr, (xtail != nullptr && (t) == ntiles - 1) ? xtail : X + (size_t)(t) * I, lane, I)
 
 constexpr int F13 = 13;
 constexpr int FP = 16;
@@ -49,14 +49,16 @@ struct PairMap {
     }
   }
 };
-template <int NP>
+// STREAM: non-temporal loads for whole-line, read-once streams of OLD data (X; g in the backward): see gcnx.hip
+template <int NP, bool STREAM = false>
 __device__ __forceinline__ void gload_pairs(f32x2 (&r)[NP], const float* __restrict__ src, int lane, int I) {
   const int npairs = (I + 1) / 2;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     if (64 * k < npairs) {                               // wave-uniform
       const int p = lane + 64 * k;
-      r[k] = *(const f32x2*)(src + 2 * (p < npairs ? p : npairs - 1));
+      const f32x2* q = (const f32x2*)(src + 2 * (p < npairs ? p : npairs - 1));
+      r[k] = STREAM ? __builtin_nontemporal_load(q) : *q;
     }
   }
 }
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
   f32x2 xr[NP], dr[NP], gr[NP];
   if (wave_id < ntiles) {
     XLOAD(wave_id);
-    gload_pairs<NP>(gr, gact + (size_t)wave_id * ld_g, lane, I);
+    gload_pairs<NP, true>(gr, gact + (size_t)wave_id * ld_g, lane, I);
     gload_pairs<NP>(dr, dg + (size_t)wave_id * ld_dg, lane, I);
   }
   for (int tile = wave_id; tile < ntiles; tile += nwaves) {
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(64 * BWD_WAVES) gcn32_bwd_kernel(int ntiles, i
     if (tile + nwaves < ntiles) {
       const size_t nt = (size_t)(tile + nwaves);
       XLOAD(tile + nwaves);
-      gload_pairs<NP>(gr, gact + nt * ld_g, lane, I);
+      gload_pairs<NP, true>(gr, gact + nt * ld_g, lane, I);
       gload_pairs<NP>(dr, dg + nt * ld_dg, lane, I);
     }
     // ---- recompute U1 [s][f'], H1 [s][f]
