@@ -168,7 +168,7 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
 // A2hi != null: columns m >= msplit of the A operand are column m - msplit of the planes A2hi / A2lo (row stride lda2)
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
                     int K, int splitk, float* partial, int Mout, int Nout, bool x3, const void* A2hi, const void* A2lo,
-                    int lda2, int msplit, hipStream_t st);
+                    int lda2, int msplit, hipStream_t st, bool b_stream = false /*B: old read-once data, non-temporal*/);
 // general shapes (general.hip): CSR adjacency (blob layout: see include/windgnn.h) and any hidden width
 size_t gcn_csr_bwd_partial_floats();
 int launch_gcn2_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W1, const float* b1,

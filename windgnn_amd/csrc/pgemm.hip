@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
                                                                 float* __restrict__ partial, int Mout, int Nout,
                                                                 int nNb, const _Float16* __restrict__ A2hi,
                                                                 const _Float16* __restrict__ A2lo, int lda2,
-                                                                int msplit) {
+                                                                int msplit, int b_stream) {
   constexpr int BM = TN_BM, BN = 32 * T;
   constexpr int ARB = BM * 2, BRB = BN * 2;                         // row bytes
   constexpr int A_PL = 32 * ARB, B_PL = 32 * BRB, STAGE = 2 * A_PL + 2 * B_PL;
@@ -370,8 +370,14 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
       if (on[it]) {
         int k = min(k0 + prow[it], kend - 1);                      // rows past the chunk: zeroed in LDS below
         if (isb[it] && shift_T > 0) k = (k % shift_T) != 0 ? k - 1 : K;   // row K = the stored t = 0 row
-        __builtin_amdgcn_global_load_lds((glb_void*)(base[it] + (size_t)k * ld[it] + pcol[it]),
-                                         (lds_void*)(st + dst[it]), 16, 0, 0);
+        // b_stream: the B operand is an old, read-once tensor (the g plane, the Hprev planes): non-temporal, so that it does
+        // not push the A operand's planes (dGI: read again by the other GEMMs) out of the Infinity Cache
+        if (isb[it] && b_stream)
+          __builtin_amdgcn_global_load_lds((glb_void*)(base[it] + (size_t)k * ld[it] + pcol[it]),
+                                           (lds_void*)(st + dst[it]), 16, 0, 2);
+        else
+          __builtin_amdgcn_global_load_lds((glb_void*)(base[it] + (size_t)k * ld[it] + pcol[it]),
+                                           (lds_void*)(st + dst[it]), 16, 0, 0);
       }
   };
 
@@ -616,7 +622,7 @@ int pgemm_tn_tiles(int Mout, int Nout) {
 template <int T>
 static int launch_tn_t(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
                        int K, int splitk, float* partial, int Mout, int Nout, bool x3, int nNb, const void* A2hi,
-                       const void* A2lo, int lda2, int msplit, hipStream_t st) {
+                       const void* A2lo, int lda2, int msplit, hipStream_t st, bool b_stream) {
   const int nMb = cdiv_i(Mout, TN_BM);
   const int kchunk = cdiv_i(cdiv_i(K, splitk), 32) * 32;
   const size_t smem = 2 * (size_t)(2 * 32 * 2 * (TN_BM + 32 * T));
@@ -630,7 +636,7 @@ static int launch_tn_t(const void* Ahi, const void* Alo, int lda, const void* Bh
   const dim3 grid(splitk, nMb * nNb), block(64 * TN_WAVES);
   if (!alo) { Alo = Ahi; A2lo = A2hi; }            // never read
 #define TN_ARGS (const _Float16*)Ahi, (const _Float16*)Alo, lda, (const _Float16*)Bhi, (const _Float16*)Blo, ldb, shift_T, K, \
-                kchunk, partial, Mout, Nout, nNb, (const _Float16*)A2hi, (const _Float16*)A2lo, lda2, msplit
+                kchunk, partial, Mout, Nout, nNb, (const _Float16*)A2hi, (const _Float16*)A2lo, lda2, msplit, (int)b_stream
 #define TN_GO(NAME, X3V, A2V, ALOV)                                                                                  \
   do {                                                                                                               \
     static std::atomic<unsigned long long> done_{0};                                                                 \
@@ -676,7 +682,7 @@ size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk) {
 // operand looks like at a window start) where k % shift_T == 0.
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
                     int K, int splitk, float* partial, int Mout, int Nout, bool x3, const void* A2hi, const void* A2lo,
-                    int lda2, int msplit, hipStream_t st) {
+                    int lda2, int msplit, hipStream_t st, bool b_stream) {
   if (lda % 8 != 0 || ldb % 8 != 0 || K < 1) return WGNN_ERR_SHAPE;
   if (A2hi && (lda2 % 8 != 0 || msplit % 8 != 0 || msplit > lda)) return WGNN_ERR_SHAPE;
   int nNb, T;
@@ -684,7 +690,7 @@ int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, 
   switch (T) {
 #define TN_CASE(t) \
   case t: return launch_tn_t<t>(Ahi, Alo, lda, Bhi, Blo, ldb, shift_T, K, splitk, partial, Mout, Nout, x3, nNb, A2hi, A2lo, \
-                                lda2, msplit, st);
+                                lda2, msplit, st, b_stream);
     TN_CASE(1) TN_CASE(2) TN_CASE(3) TN_CASE(4) TN_CASE(5) TN_CASE(6) TN_CASE(7)
 #undef TN_CASE
   }
