@@ -579,7 +579,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       // planes and rows >= msplit from the dGHn planes; the reduce kernel maps the GEMM rows back to W_hh's rows.
       if (L.dghn) {
         rc = launch_pgemm_tn(dGIh, dGIlo, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
-                             L.sk_hh, part_hh, L.m_hh, (int)L.H + 1, full, dGHh, dGHnlo, L.hn, L.msplit, st);   // (Hprev planes: partly still cached, plain loads: 34.2 vs 35.6 us)
+                             L.sk_hh, part_hh, L.m_hh, (int)L.H + 1, full, dGHh, dGHnlo, L.hn, L.msplit, st, /*b_stream=*/true);
       } else {
         rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
                              L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, full, nullptr, nullptr, 0, 0, st);

@@ -341,7 +341,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         const int b = b0 + m;
         if (b < B) {
           const h8 v = *(const h8*)((plane ? nlo : nhi) + m * HS + 8 * ch);
-          *(h8*)((plane ? yp_lo : yp_hi) + (size_t)b0 * T * HP + (m * T + t) * HP + 8 * ch) = v;
+          // non-temporal: the planes are next read by the dW_hh GEMM, four kernels later; kept out of the Infinity Cache they
+          // leave it to the gate stash and Y, which the BPTT kernel reads back right after this one
+          __builtin_nontemporal_store(v, (h8*)((plane ? yp_lo : yp_hi) + (size_t)b0 * T * HP + (m * T + t) * HP + 8 * ch));
         }
       }
     }
