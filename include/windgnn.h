@@ -70,7 +70,8 @@ typedef enum wgnn_status {
 typedef enum wgnn_math {
   WGNN_MATH_F32 = 0,   /* fp32-input MFMA: bitwise an fp32 fmaf chain */
   WGNN_MATH_F16X3 = 1, /* split-fp16 (hi+lo) MFMA, 3 products, fp32 accumulate: fp32-grade error */
-  WGNN_MATH_F16 = 2,   /* plain fp16 operands, one MFMA pass, fp32 accumulate: ~1e-3 error (16-bit config) */
+  WGNN_MATH_F16 = 2,   /* plain fp16 operands, one MFMA pass, fp32 accumulate: ~1e-3 error (16-bit config); with the
+                          register-resident recurrence (H <= 127) the intermediates GI and dg, too, are single fp16 planes */
   WGNN_MATH_F16X3G = 3 /* F16X3, except that from B*T >= 4096 rows the backward's gate gradients (dGI, dGH_n) leave the BPTT
                           kernel as ONE fp16 plane and the three GEMMs they feed run fewer MFMA passes: dW_hh and dg two
                           (hi x (hi + lo)), dW_ih one (hi x hi); dg itself, too, is written as one fp16 plane (dense
