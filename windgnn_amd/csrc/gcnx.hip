@@ -531,6 +531,11 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
   __shared__ __attribute__((aligned(16))) h8 sCA[2 * NF * 64];   // [frag][hi|lo][lane]
   __shared__ __attribute__((aligned(16))) h8 sCT[2 * NF * 64];
+  // odd NT: the last k step's fragments are half fragments (4 halfs per lane); a compact copy lets the products read them
+  // as ds_read_b64 -- a quarter of the fragment bytes of a tile (9 of 36 KB at NT = 3) less through the CU's LDS pipe
+  // (split instances only: the one-pass ones, whose half steps run on the K = 32 form, measured 89.7 -> 92.5 us with it)
+  constexpr bool HALF = X3 && (NT & 1) != 0;
+  __shared__ __attribute__((aligned(8))) h4v sHA[HALF ? 2 * NT * 64 : 1], sHT[HALF ? 2 * NT * 64 : 1];
   constexpr int BWD_WAVES = bwd_waves(NT, X3);
   __shared__ __attribute__((aligned(16))) float sbuf[BWD_WAVES * 2 * SP * XS];
   static_assert(2 * SP * XS >= PART, "the per-wave staging buffer doubles as its reduction row");
@@ -548,6 +553,10 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
       for (int ks = 0; ks < KS; ++ks) {
         sCA[((mi * KS + ks) * 2 + 0) * 64 + lane] = T[mi][ks].hi;
         sCA[((mi * KS + ks) * 2 + 1) * 64 + lane] = T[mi][ks].lo;
+        if (HALF && ks == KS - 1) {
+          sHA[(mi * 2 + 0) * 64 + lane] = __builtin_shufflevector(T[mi][ks].hi, T[mi][ks].hi, 0, 1, 2, 3);
+          sHA[(mi * 2 + 1) * 64 + lane] = __builtin_shufflevector(T[mi][ks].lo, T[mi][ks].lo, 0, 1, 2, 3);
+        }
       }
   } else if (wave == 1) {
     Frag T[NT][KS];
@@ -558,21 +567,27 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
       for (int ks = 0; ks < KS; ++ks) {
         sCT[((mi * KS + ks) * 2 + 0) * 64 + lane] = T[mi][ks].hi;
         sCT[((mi * KS + ks) * 2 + 1) * 64 + lane] = T[mi][ks].lo;
+        if (HALF && ks == KS - 1) {
+          sHT[(mi * 2 + 0) * 64 + lane] = __builtin_shufflevector(T[mi][ks].hi, T[mi][ks].hi, 0, 1, 2, 3);
+          sHT[(mi * 2 + 1) * 64 + lane] = __builtin_shufflevector(T[mi][ks].lo, T[mi][ks].lo, 0, 1, 2, 3);
+        }
       }
   }
   __syncthreads();
-  auto ldA = [&](int mi, int ks) {
+  auto ld_frag = [&](const h8* full, const h4v* half, int mi, int ks) {
     Frag f;
-    f.hi = sCA[((mi * KS + ks) * 2 + 0) * 64 + lane];
-    f.lo = sCA[((mi * KS + ks) * 2 + 1) * 64 + lane];
+    if (HALF && ks == KS - 1) {      // slots j >= 4 of a half fragment are never multiplied by a non-zero partner
+      const h4v a = half[(mi * 2 + 0) * 64 + lane], b = half[(mi * 2 + 1) * 64 + lane];
+      f.hi = __builtin_shufflevector(a, a, 0, 1, 2, 3, 0, 1, 2, 3);
+      f.lo = __builtin_shufflevector(b, b, 0, 1, 2, 3, 0, 1, 2, 3);
+    } else {
+      f.hi = full[((mi * KS + ks) * 2 + 0) * 64 + lane];
+      f.lo = full[((mi * KS + ks) * 2 + 1) * 64 + lane];
+    }
     return f;
   };
-  auto ldT = [&](int mi, int ks) {
-    Frag f;
-    f.hi = sCT[((mi * KS + ks) * 2 + 0) * 64 + lane];
-    f.lo = sCT[((mi * KS + ks) * 2 + 1) * 64 + lane];
-    return f;
-  };
+  auto ldA = [&](int mi, int ks) { return ld_frag(sCA, sHA, mi, ks); };
+  auto ldT = [&](int mi, int ks) { return ld_frag(sCT, sHT, mi, ks); };
 
   Frag FW1, FW2T;
   {
