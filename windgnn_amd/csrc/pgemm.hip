@@ -224,6 +224,62 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     }
   }
 
+  // ---- epilogue through LDS (the ring is idle now): the accumulators of ROWS tile rows at a time are laid out row-major in
+  // LDS and leave as 16-byte stores, 1 KB per wave-instruction -- a quarter of the store instructions of the per-lane form
+  // below (dword stores in 64-byte segments), which is store-ISSUE-bound: measured 19-22 us of pgemm_nt<10>'s 87 with the
+  // main loop ablated.  Taken when C rows are 16-byte aligned and nothing is accumulated onto C.
+  {
+    constexpr int PW = BN + 4;                                      // LDS row pitch in floats: rows 4 apart are 16 banks apart
+    constexpr int ROWS = nt_smem(T, X3, ALO) >= (size_t)96 * PW * 4 ? 96 : 48;
+    constexpr int NPASS = BM / ROWS;                                // 2 (pass = i) or 4 (pass = 2 i + (wm >= 3))
+    static_assert(nt_smem(T, X3, ALO) >= (size_t)ROWS * PW * 4, "the ring holds one pass of the tile");
+    constexpr int CW = OUT16 ? 8 : 4;                               // columns per 16-byte store
+    const int ldb16 = OUT16 ? ldc / 8 * 8 : ldc / 4 * 4;
+    // (fp32 C of the split instances: pgemm_nt<10> 89.3 -> 85.1 / 87.5 -> 85.2 / 87.2 -> 84.9 us; the packed fp16 epilogue and
+    // the one-pass instances measured 0 ... +1 us with it and keep the per-lane form)
+    if (X3 && !OUT16 && !accumulate && ldb16 == ldc && ((size_t)C & 15) == 0) {     // wave-uniform
+      float* tile = (float*)smem;
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int i = NPASS == 2 ? pass : pass >> 1;
+        const bool mine = NPASS == 2 || (wm >= 3) == (bool)(pass & 1);
+        const int wl = NPASS == 2 ? wm : wm % 3;
+        __syncthreads();                                            // the ring / the previous pass's rows are no longer read
+        if (mine) {
+#pragma unroll
+          for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              tile[(16 * wl + 4 * c4 + r) * PW + BNW * wn + 16 * j + r16] = acc[i][j][r] * s_out;
+        }
+        __syncthreads();
+        for (int q = tid; q < ROWS * (BN / CW); q += 64 * NT_WAVES) {
+          const int lr = q / (BN / CW), cc = q % (BN / CW);
+          const int wq = lr >> 4, x = lr & 15;
+          const int row = m0 + 32 * (NPASS == 2 ? wq : wq + 3 * (pass & 1)) + 16 * i + x;
+          const int col = n0 + CW * cc;
+          if (row >= M || col >= N) continue;
+          const float* src = tile + lr * PW + CW * cc;
+          if (OUT16) {
+            const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+            typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+            h8v h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = (_Float16)a[e]; h[4 + e] = (_Float16)b[e]; }
+            _Float16* dst = (_Float16*)C + (size_t)row * ldc + col;
+            if (col + CW <= ldc) *(h8v*)dst = h;
+            else for (int e = 0; e < CW && col + e < N; ++e) dst[e] = h[e];
+          } else {
+            const f32x4 a = *(const f32x4*)src;
+            float* dst = C + (size_t)row * ldc + col;
+            if (col + CW <= ldc) *(f32x4*)dst = a;
+            else for (int e = 0; e < CW && col + e < N; ++e) dst[e] = a[e];
+          }
+        }
+      }
+      return;
+    }
+  }
   if (OUT16) {
     _Float16* Ch = (_Float16*)C;
     const bool odd = lane & 1;
