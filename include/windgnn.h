@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 120 /* 0.1.2: wgnn_params.prepared, wgnn_finish, WGNN_BWD_DEFER */
+#define WGNN_VERSION 121 /* 0.1.2: wgnn_params.prepared, wgnn_finish, WGNN_BWD_DEFER; 121: WGNN_FINISH_ADAM_GRU / _CONV */
 
 /* Status block: the first 256 bytes of every `workspace` passed to wgnn_fwd / wgnn_bwd* belong to the library as a
  * sticky status area that kernels only ever OR into; word 0 (uint32) holds the bits below.  The caller zeroes the
@@ -218,9 +218,15 @@ int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const void* X, const w
  *               just reduced, or as they stand in `g` for the parts not named in `which`; if p->prepared is set, the
  *               staged images of the NEW w_ih / b_ih are written too, so the next wgnn_fwd* / wgnn_bwd* need no
  *               re-split / re-pad pass.
+ *   which & WGNN_FINISH_ADAM_GRU / WGNN_FINISH_ADAM_CONV (with adam, and with no reduce bit): the optimiser step of the four
+ *               GRU tensors (+ the staged images) only / of the four conv tensors only, so that a data-parallel caller can
+ *               update the GRU tensors while the conv gradients' all-reduce is still in flight.
  * One rank: wgnn_bwd_mse_part(.., 7 | 8 | WGNN_BWD_DEFER), wgnn_finish(.., 6, &adam).  Data parallel: part 1 | 4 | DEFER,
  * wgnn_finish(4, NULL), all-reduce of the GRU gradients overlapped with part 2 | DEFER, wgnn_finish(2, NULL), all-reduce
- * of the conv gradients, wgnn_finish(0, &adam).  The fused and the split form give bitwise identical results. */
+ * of the conv gradients overlapped with wgnn_finish(WGNN_FINISH_ADAM_GRU, &adam), wgnn_finish(WGNN_FINISH_ADAM_CONV, &adam)
+ * (or one wgnn_finish(0, &adam) after both).  The fused and the split forms give bitwise identical results. */
+#define WGNN_FINISH_ADAM_GRU 16
+#define WGNN_FINISH_ADAM_CONV 32
 int wgnn_finish(const wgnn_dims* d, const wgnn_params* p, const wgnn_grads* g, int which, const wgnn_adam* adam,
                 void* workspace, size_t workspace_bytes, void* stream);
 

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(L.EXPORTS), (declared ^ set(L.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.wgnn_version() == 120
+    assert lib.wgnn_version() == 121
 
 
 def test_dims_validation_no_gpu_needed():
@@ -74,6 +74,12 @@ def test_finish_and_prepared_entry_points_validate_without_a_gpu():
     assert lib.wgnn_finish(ctypes.byref(x3), ctypes.byref(p), None, 6, None, None, 0, None) == -1
     assert lib.wgnn_finish(ctypes.byref(x3), ctypes.byref(p), ctypes.byref(g), 8, None, None, 0, None) == -2
     assert lib.wgnn_finish(ctypes.byref(x3), ctypes.byref(p), ctypes.byref(g), 0, None, None, 0, None) == -2
+    # the per-family optimiser step needs an optimiser, no reduce bit, and one family at a time
+    assert lib.wgnn_finish(ctypes.byref(x3), ctypes.byref(p), ctypes.byref(g), L.FINISH_ADAM_GRU, None, None, 0, None) == -2
+    ad = L.Adam()
+    ad.step = 1
+    for bad_which in (L.FINISH_ADAM_GRU | 4, L.FINISH_ADAM_CONV | 2, L.FINISH_ADAM_GRU | L.FINISH_ADAM_CONV, 64):
+        assert lib.wgnn_finish(ctypes.byref(x3), ctypes.byref(p), ctypes.byref(g), bad_which, ctypes.byref(ad), None, 0, None) == -2
     assert lib.wgnn_prepare_weights(ctypes.byref(x3), ctypes.byref(p), None, 0, None) == -1
     bad = L.Dims(4, 24, 34, 12, 102, 1, 0, 0)
     assert lib.wgnn_finish(ctypes.byref(bad), ctypes.byref(p), ctypes.byref(g), 6, None, None, 0, None) == -2

@@ -46,7 +46,13 @@ def _worker(rank, world, port, out_dir):
         grads = orc.backward(A, Xs, p, Y, cache, dY * w)
         bucket[wd.LOSS_SLOT] = loss_local
         bucket[wd.HEADER:] = wd.flatten([grads[k] for k in PARAM_KEYS])
-        ex.finish(ex.start_gru(), w)
+        if step % 2 == 0:
+            ex.finish(ex.start_gru(), w)
+        else:                                # TrainStep's form: the conv all-reduce started async, both joined afterwards
+            wg = ex.start_gru()
+            wc = ex.start_conv(w)
+            wg.wait()
+            wc.wait()
         np.save(os.path.join(out_dir, "bucket_%d_rank%d.npy" % (step, rank)), bucket.numpy())
     dist.barrier()
     dist.destroy_process_group()

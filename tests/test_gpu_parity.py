@@ -1110,7 +1110,11 @@ def test_finish_kernel_equals_the_separate_reduce_adam_and_prepare_passes(S, T, 
             finish_step(d2, ps, gs, 4)
             gcn_gru_backward_mse_raw(d2, A, X, ps, Y, L, stash, gs, loss, 1.0, part=2 | _lib.BWD_DEFER, prepared=img)
             finish_step(d2, ps, gs, 2)
-            finish_step(d2, ps, gs, 0, adam, img)
+            if split == 2:      # the optimiser step per tensor family (the conv all-reduce runs under the first one)
+                finish_step(d2, ps, gs, _lib.FINISH_ADAM_GRU, adam, img)
+                finish_step(d2, ps, gs, _lib.FINISH_ADAM_CONV, adam, img)
+            else:
+                finish_step(d2, ps, gs, 0, adam, img)
         else:
             gcn_gru_backward_mse_raw(d2, A, X, ps, Y, L, stash, gs, loss, 1.0, part=7 | 8 | _lib.BWD_DEFER, prepared=img)
             finish_step(d2, ps, gs, 6, adam, img)
@@ -1133,11 +1137,12 @@ def test_finish_kernel_equals_the_separate_reduce_adam_and_prepare_passes(S, T, 
         assert torch.equal(fused[4], again)
         if math == "f32":
             assert max_abs(fused[4].view(torch.float32).cpu(), img_ref.view(torch.float32).cpu()) <= 2e-7
-    split = run(True)
-    for a, b in zip(split[0] + split[1] + split[2] + split[3], fused[0] + fused[1] + fused[2] + fused[3]):
-        assert torch.equal(a, b)
-    assert (split[4] is None and fused[4] is None) or torch.equal(split[4], fused[4])
-    assert split[5] == fused[5]
+    for form in (1, 2):
+        split = run(form)
+        for a, b in zip(split[0] + split[1] + split[2] + split[3], fused[0] + fused[1] + fused[2] + fused[3]):
+            assert torch.equal(a, b), form
+        assert (split[4] is None and fused[4] is None) or torch.equal(split[4], fused[4])
+        assert split[5] == fused[5]
 
 
 @pytest.mark.parametrize("math", ["f32", "f16x3"])

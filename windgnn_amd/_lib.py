@@ -44,6 +44,8 @@ class Adam(C.Structure):
 
 
 BWD_DEFER = 16              # WGNN_BWD_DEFER
+FINISH_ADAM_GRU = 16        # WGNN_FINISH_ADAM_GRU / _CONV: wgnn_finish's optimiser step of one tensor family only
+FINISH_ADAM_CONV = 32
 
 
 EXPORTS = {
@@ -110,7 +112,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.wgnn_version() < 120:
+    if lib.wgnn_version() < 121:
         raise RuntimeError("windgnn_amd: libwindgnn_hip.so is too old")
     _lib = lib
     return lib

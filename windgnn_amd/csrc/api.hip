@@ -429,7 +429,9 @@ int wgnn_finish(const wgnn_dims* d, const wgnn_params* p, const wgnn_grads* g, i
                 void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
-  if ((which & ~6) != 0 || (which == 0 && !adam)) return WGNN_ERR_SHAPE;
+  const int only = which & (WGNN_FINISH_ADAM_GRU | WGNN_FINISH_ADAM_CONV);   // optimiser step of one tensor family
+  if ((which & ~(6 | WGNN_FINISH_ADAM_GRU | WGNN_FINISH_ADAM_CONV)) != 0 || (which == 0 && !adam)) return WGNN_ERR_SHAPE;
+  if (only && (!adam || (which & 6) != 0 || only == (WGNN_FINISH_ADAM_GRU | WGNN_FINISH_ADAM_CONV))) return WGNN_ERR_SHAPE;
   if (!g || !workspace || (adam && !p)) return WGNN_ERR_NULL;
   if (!g->conv1_weight || !g->conv1_bias || !g->conv2_weight || !g->conv2_bias || !g->w_ih || !g->w_hh || !g->b_ih ||
       !g->b_hh)
@@ -462,6 +464,8 @@ int wgnn_finish(const wgnn_dims* d, const wgnn_params* p, const wgnn_grads* g, i
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.b1 = adam->beta1; a.b2 = adam->beta2; a.eps = adam->eps;
     a.elem_mask = ((which & 4) ? 0u : 0xF0u) | ((which & 2) ? 0u : 0x0Fu);   // tensors whose gradient is final in g
+    if (only == WGNN_FINISH_ADAM_GRU) a.elem_mask = 0xF0u;
+    if (only == WGNN_FINISH_ADAM_CONV) a.elem_mask = 0x0Fu;
     if (p->prepared && L.prep_kind) {
       a.prep_kind = L.prep_kind;
       float* img_f = (float*)p->prepared + L.prep_f;

@@ -78,6 +78,13 @@ class BucketExchange:
         """Sum the GRU gradients (final after backward parts 1|4); returns the async work handle."""
         return dist.all_reduce(self.bucket[HEADER + self.n_conv:], group=self.group, async_op=True)
 
+    def start_conv(self, weight: float):
+        """Weight this shard's mean loss and start the small all-reduce of [loss | conv grads] (final after backward part 2);
+        returns the async work handle.  The caller may run the GRU tensors' optimiser step under it."""
+        if weight != 1.0:
+            self.bucket[LOSS_SLOT].mul_(weight)
+        return dist.all_reduce(self.bucket[LOSS_SLOT:HEADER + self.n_conv], group=self.group, async_op=True)
+
     def finish(self, work, weight: float) -> None:
         """Weight this shard's mean loss, sum the conv gradients + the loss in one small all-reduce, join `work`:
         afterwards the bucket holds the big-batch gradient and word 3 the big-batch mean loss on every rank."""

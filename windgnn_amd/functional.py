@@ -224,7 +224,8 @@ def refresh_prepared(d, params, prepared) -> None:
 def finish_step(d, params, grads, which: int, adam=None, prepared=None, device=None) -> None:
     """wgnn_finish: reduce the deferred partial sums of the backward parts in `which` (4: GRU, 2: conv) into `grads` and,
     with adam = dict(exp_avg=[8 tensors], exp_avg_sq=[8 tensors], step, lr, beta1, beta2, eps), apply Adam to `params`
-    in place (and refresh `prepared`) -- one launch."""
+    in place (and refresh `prepared`) -- one launch.  `which` = _lib.FINISH_ADAM_GRU / FINISH_ADAM_CONV (with adam, no
+    reduce bit): the optimiser step of that tensor family only."""
     lib = _lib.load()
     ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
     ws = _Workspace.get(device if device is not None else grads[0].device, ws_bytes)

@@ -121,8 +121,13 @@ class TrainStep:
             work = self.exchange.start_gru()
             gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=2 | DEFER, prepared=pre)
             finish_step(d, self.p_views, self.g_views, 2, device=self.device)
-            self.exchange.finish(work, gs)      # loss: sum of the weighted shard means = the big-batch mean
-            finish_step(d, self.p_views, self.g_views, 0, self._adam(), pre, self.device)      # src/main.py:80
+            # the conv gradients' (tiny, latency-bound) all-reduce runs under the GRU tensors' optimiser step
+            wconv = self.exchange.start_conv(gs)     # loss: sum of the weighted shard means = the big-batch mean
+            work.wait()
+            adam = self._adam()
+            finish_step(d, self.p_views, self.g_views, _lib.FINISH_ADAM_GRU, adam, pre, self.device)   # src/main.py:80
+            wconv.wait()
+            finish_step(d, self.p_views, self.g_views, _lib.FINISH_ADAM_CONV, adam, pre, self.device)
         else:
             # One rank: BPTT, then the dg GEMM + GCN backward, and the weight-gradient GEMMs LAST, so that wgnn_finish reads
             # their split-K partial sums (115 MB at B = 4096) while they still sit in the Infinity Cache; deferring them
