@@ -261,6 +261,9 @@ def main():
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
     if use_dist:
+        if world == 1:                                  # --force-dist without a launcher: a one-rank group on this GPU
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=dev)
 
     from windgnn_amd import GCN_GRU, _lib
@@ -430,7 +433,7 @@ def main():
                                    "backward + grad all-reduce (N>1) + Adam; %s I/O"
                                    % (S, "" if args.workload == "c3" else " (symmetric 8-NN graph, CSR)", H, B, args.io),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "math": args.math,
-                       "collective": ("rccl all-reduce x2 per step (GRU grads overlapped with backward part 2; conv grads + loss)"
+                       "collective": ("one rccl all-reduce per step: [loss | conv | GRU gradients], 0.67 MB, between wgnn_finish(6) and wgnn_finish(0, adam)"
                                       if use_dist else "none (one rank)")},
             "loss": round(float(loss), 6),
             "roofline": roofline,

@@ -46,9 +46,11 @@ def _worker(rank, world, port, out_dir):
         grads = orc.backward(A, Xs, p, Y, cache, dY * w)
         bucket[wd.LOSS_SLOT] = loss_local
         bucket[wd.HEADER:] = wd.flatten([grads[k] for k in PARAM_KEYS])
-        if step % 2 == 0:
+        if step == 0:
+            ex.all_reduce_all(w)             # TrainStep's default: ONE all-reduce of [loss | conv | GRU gradients]
+        elif step % 2 == 0:
             ex.finish(ex.start_gru(), w)
-        else:                                # TrainStep's form: the conv all-reduce started async, both joined afterwards
+        else:                                # the two-collective form: the conv all-reduce started async, both joined afterwards
             wg = ex.start_gru()
             wc = ex.start_conv(w)
             wg.wait()

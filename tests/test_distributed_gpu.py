@@ -23,9 +23,10 @@ def _free_port():
     return p
 
 
-def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32), stated=False):
+def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32), stated=False, overlap=False):
     """`batches`: the global batch of each step (sharded over the ranks); `stated`: pass n_global to TrainStep.step
-    instead of letting the exchange all-reduce the count."""
+    instead of letting the exchange all-reduce the count; `overlap`: the two-collective form (the GRU gradients' all-reduce
+    overlapped with backward part 2) instead of the default single all-reduce."""
     from windgnn_amd.distributed import ensure_rccl_env, shard_windows
     ensure_rccl_env()                     # the environment bench.py establishes, before this process touches the GPU
     from windgnn_amd import GCN_GRU
@@ -44,7 +45,7 @@ def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32
     m = GCN_GRU(13, 13, 13, 7 * 13, 21, math="f16x3")
     m.load_state_dict({k: v.clone() for k, v in fx["params"].items()})
     m = m.to(dev)
-    tr = TrainStep(m, process_group=group)
+    tr = TrainStep(m, process_group=group, overlap_collectives=overlap)
     assert tr.collective == (world > 1 or backend == "nccl")
     A = torch.from_numpy(fx["A"]).to(dev)
     X, L = torch.from_numpy(fx["X"]), torch.from_numpy(fx["L"])
@@ -66,15 +67,16 @@ def test_two_rank_training_equals_single_process(tmp_path):
     assert torch.cuda.is_available()
     _train(0, 1, 0, str(tmp_path))
     mp.spawn(_train, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_train, args=(2, _free_port(), str(tmp_path), "gloo", "world2_overlap", (32, 32), False, True), nprocs=2, join=True)
     p1 = torch.from_numpy(np.load(os.path.join(str(tmp_path), "p_world1.npy")))
-    p2 = torch.from_numpy(np.load(os.path.join(str(tmp_path), "p_world2.npy")))
-    # Adam moves each weight by ~1e-3 per step; shard-sum vs big-batch gradients differ only by fp32 rounding
-    assert max_abs(p1, p2) <= 2e-5
-
-    # the loss every rank returns is the big-batch mean loss, not its shard's
     l1 = np.load(os.path.join(str(tmp_path), "loss_world1.npy"))
-    l2 = np.load(os.path.join(str(tmp_path), "loss_world2.npy"))
-    assert np.abs(l1 - l2).max() <= 1e-6 * max(1.0, float(np.abs(l1).max()))
+    for tag in ("world2", "world2_overlap"):      # the single all-reduce (default) and the two-collective form
+        p2 = torch.from_numpy(np.load(os.path.join(str(tmp_path), "p_%s.npy" % tag)))
+        # Adam moves each weight by ~1e-3 per step; shard-sum vs big-batch gradients differ only by fp32 rounding
+        assert max_abs(p1, p2) <= 2e-5, tag
+        # the loss every rank returns is the big-batch mean loss, not its shard's
+        l2 = np.load(os.path.join(str(tmp_path), "loss_%s.npy" % tag))
+        assert np.abs(l1 - l2).max() <= 1e-6 * max(1.0, float(np.abs(l1).max())), tag
 
 
 def test_two_rank_training_with_unequal_and_changing_shards(tmp_path):
@@ -98,18 +100,20 @@ def test_two_rank_training_with_unequal_and_changing_shards(tmp_path):
 
 
 def test_rccl_allreduce_path_executes_and_is_bitwise_neutral_with_one_rank(tmp_path):
-    """The RCCL ("nccl") code path of TrainStep.step -- init_process_group("nccl"), the async all-reduce of the GRU
-    gradients overlapped with backward part 2, the conv-gradient + loss all-reduce -- executed for real in a fresh
+    """The RCCL ("nccl") code paths of TrainStep.step -- init_process_group("nccl"), the single all-reduce of the bucket
+    (default) and the two-collective form (async all-reduce of the GRU gradients overlapped with backward part 2, then the
+    conv-gradient + loss all-reduce under the GRU tensors' optimiser step) -- executed for real in a fresh
     child process on the one GPU this box has (world_size 1: RCCL refuses two ranks on one device).  A one-rank sum
     is the identity, so the parameters after two steps must equal the no-group run bit for bit."""
     assert torch.cuda.is_available()
     mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "gloo", "plain"), nprocs=1, join=True)
     mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1"), nprocs=1, join=True)
+    mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1_overlap", (32, 32), False, True), nprocs=1, join=True)
     p0 = np.load(os.path.join(str(tmp_path), "p_plain.npy"))
-    p1 = np.load(os.path.join(str(tmp_path), "p_rccl1.npy"))
-    assert np.array_equal(p0, p1)
-    assert np.array_equal(np.load(os.path.join(str(tmp_path), "loss_plain.npy")),
-                          np.load(os.path.join(str(tmp_path), "loss_rccl1.npy")))
+    for tag in ("rccl1", "rccl1_overlap"):        # the single all-reduce (default) and the two-collective form
+        assert np.array_equal(p0, np.load(os.path.join(str(tmp_path), "p_%s.npy" % tag))), tag
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "loss_plain.npy")),
+                              np.load(os.path.join(str(tmp_path), "loss_%s.npy" % tag))), tag
 
 
 def test_bench_multi_gpu_code_path_runs_under_torchrun_with_rccl():

@@ -1,8 +1,9 @@
 """Data-parallel host logic.  Windows are independent (h0 = 0 per window,
 src/step6_gcn_gru_combined_model.py:23 passes no h0), so the path shards over B with no data-path
-collective; the only exchange is the sum of the flat gradient bucket, as TWO all-reduces per step
-(`BucketExchange`): the GRU gradients (99.8 % of the bytes) as soon as they are final, overlapped with the rest
-of the backward, then the conv gradients together with the loss scalar.
+collective; the only exchange is the sum of the flat gradient bucket (`BucketExchange`): by default ONE all-reduce of
+[loss | conv | GRU gradients] per step (`all_reduce_all`); the two-collective form (`start_gru` / `start_conv` / `finish`: the
+GRU gradients as soon as they are final, overlapped with the rest of the backward, then the conv gradients with the loss) is
+kept and tested, but its cross-stream dependencies cost more than the overlap saves (trainer.py).
 
 Backend-agnostic (nccl == RCCL over xGMI on the GPU box, gloo in the CPU tests).  `TrainStep` (trainer.py) and
 `bench.py` run exactly this class; tests/test_distributed_cpu.py runs it with the oracle standing in for the kernels.
@@ -73,6 +74,13 @@ class BucketExchange:
         if n_local < 0 or n_global < n_local or n_global < 1:
             raise RuntimeError("windgnn_amd: shard of %d windows in a global batch of %d" % (n_local, n_global))
         return grad_scale_for_shard(n_local, n_global)
+
+    def all_reduce_all(self, weight: float) -> None:
+        """Weight this shard's mean loss and sum [loss | conv grads | GRU grads] in ONE all-reduce (the current stream
+        waits for it; no host sync).  What TrainStep runs by default: see trainer.py for the measurement behind it."""
+        if weight != 1.0:
+            self.bucket[LOSS_SLOT].mul_(weight)
+        dist.all_reduce(self.bucket[LOSS_SLOT:], group=self.group)
 
     def start_gru(self):
         """Sum the GRU gradients (final after backward parts 1|4); returns the async work handle."""

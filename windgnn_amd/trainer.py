@@ -2,12 +2,15 @@
 forward -> MSE + backward (wgnn_bwd_mse_part) -> (data-parallel all-reduce) -> Adam, every op a C-ABI call.
 
 Data parallel: windows are independent, so each rank runs its own shard of
-windows; the 8 gradients live in ONE flat fp32 bucket (167 440 floats at S=34).  Per step the bucket is summed by
-TWO all-reduces on RCCL's stream: the GRU gradients (99.8 % of the bytes) as soon as the weight-gradient GEMMs are
-done, overlapped with the rest of the backward (dg GEMM + GCN backward), then the 364 conv gradients together with
-the scalar loss.  dY is pre-scaled by n_local / n_global (= 1 / world_size for equal shards) so the summed bucket
-equals the gradient of the big-batch mean loss, and the returned loss is the big-batch mean loss on every rank.
-The collectives themselves live in distributed.BucketExchange (every rank issues every collective on every step).
+windows; the 8 gradients live in ONE flat fp32 bucket (167 440 floats at S=34).  Per step the bucket is summed by ONE
+all-reduce of [loss | conv gradients | GRU gradients] (0.67 MB) between the reduce-only wgnn_finish(6) and the optimiser's
+wgnn_finish(0, adam).  (Round 3 measured the alternative it replaced -- two all-reduces, the GRU gradients' one started
+asynchronously after the weight-gradient GEMMs and overlapped with the dg GEMM + GCN backward -- on a one-rank group, where the
+collectives themselves cost nothing: +65 us per 632 us step for its cross-stream dependencies and extra launches against +10 us
+for this form; `overlap_collectives=True` still selects it.)  dY is pre-scaled by n_local / n_global (= 1 / world_size for
+equal shards) so the summed bucket equals the gradient of the big-batch mean loss, and the returned loss is the big-batch mean
+loss on every rank.  The collectives themselves live in distributed.BucketExchange (every rank issues every collective on
+every step).
 
 The loss a step returns is a 0-dim VIEW of the bucket's header: read it (float(loss)) before the next step."""
 from __future__ import annotations
@@ -23,7 +26,7 @@ from .modules import GCN_GRU
 
 class TrainStep:
     def __init__(self, model: GCN_GRU, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, check_every: int = 100):
+                 process_group=None, check_every: int = 100, overlap_collectives: bool = False):
         self.model = model
         self.params = list(model.hot_path_parameters())
         sizes = [p.numel() for p in self.params]
@@ -56,6 +59,7 @@ class TrainStep:
             self.world = torch.distributed.get_world_size(process_group)
         # an explicitly passed group runs the collective path even with one rank (the all-reduces execute)
         self.collective = self.world > 1 or process_group is not None
+        self.overlap_collectives = overlap_collectives
         self.exchange = BucketExchange(self._gbuf, self.n_conv, process_group) if self.collective else None
         self.check_every = check_every          # f16x3 / f16: read the library's range-status word every N steps
         self.device = dev
@@ -108,7 +112,19 @@ class TrainStep:
         DEFER = _lib.BWD_DEFER
         self.steps += 1
         loss = self._loss
-        if self.collective:
+        if self.collective and not self.overlap_collectives:
+            # the single-rank schedule, with ONE all-reduce of [loss | conv | GRU gradients] between the reduce-only finish and
+            # the optimiser's: one collective, one stream dependency each way per step
+            gs = self.exchange.shard_weight(X.shape[0], n_global)
+            Y, stash, d = self._forward(A, X, L)
+            pre = self._prepared
+            for part in (1 | 8, 2, 4):
+                gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, gs, part=part | DEFER,
+                                         prepared=pre)
+            finish_step(d, self.p_views, self.g_views, 6, device=self.device)
+            self.exchange.all_reduce_all(gs)    # loss: sum of the weighted shard means = the big-batch mean
+            finish_step(d, self.p_views, self.g_views, 0, self._adam(), pre, self.device)      # src/main.py:80
+        elif self.collective:
             # Overlap: the GRU gradients (99.8 % of the bucket) are final after parts 1|4 of the backward, so
             # their all-reduce runs on RCCL's stream while part 2 (dg GEMM + GCN backward, ~30 % of the
             # step) still computes; the 364 conv gradients and the loss follow in a second, tiny all-reduce.
