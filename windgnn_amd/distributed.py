@@ -80,7 +80,7 @@ class BucketExchange:
         waits for it; no host sync).  What TrainStep runs by default: see trainer.py for the measurement behind it."""
         if weight != 1.0:
             self.bucket[LOSS_SLOT].mul_(weight)
-        dist.all_reduce(self.bucket[LOSS_SLOT:], group=self.group)
+        dist.all_reduce(self.bucket, group=self.group)       # the whole, 16-byte aligned bucket (header words 0-2 are zeros)
 
     def start_gru(self):
         """Sum the GRU gradients (final after backward parts 1|4); returns the async work handle."""
