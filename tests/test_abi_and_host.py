@@ -28,6 +28,50 @@ def test_every_declared_symbol_is_exported():
     assert lib.wgnn_version() == 121
 
 
+def _header_prototypes():
+    """{name: (return type, [argument type strings])} of every wgnn_* function include/windgnn.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "windgnn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", " ", hdr)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(wgnn_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", hdr):
+        ret, name, args = " ".join(m.group(1).split()), m.group(2), " ".join(m.group(3).split())
+        protos[name] = (ret, [] if args in ("", "void") else [a.strip() for a in args.split(",")])
+    return protos
+
+
+def _ctype_kind(t):
+    """Coarse class of a ctypes argument type, comparable with a C declaration."""
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "_type_") and not isinstance(t._type_, str):
+        return "ptr"
+    return {ctypes.c_float: "float", ctypes.c_double: "double", ctypes.c_int64: "i64", ctypes.c_size_t: "size",
+            ctypes.c_int: "i32", ctypes.c_int32: "i32"}[t]
+
+
+def _c_kind(decl):
+    if "*" in decl:
+        return "ptr"
+    words = decl.replace("const", " ").split()
+    base = " ".join(words[:-1]) if len(words) > 1 else words[0]      # drop the parameter name
+    return {"float": "float", "double": "double", "int64_t": "i64", "size_t": "size", "int": "i32", "int32_t": "i32"}[base]
+
+
+def test_ctypes_prototypes_match_the_header_argument_for_argument():
+    """windgnn_amd/_lib.py mirrors include/windgnn.h by hand; an argument added to one and not the other would pass the
+    name check above and corrupt the call on the GPU box.  Every prototype is parsed out of the header and compared with
+    _lib.EXPORTS: argument count, and the class of every argument (pointer / float / double / int32 / int64 / size_t)."""
+    from windgnn_amd import _lib as L
+    protos = _header_prototypes()
+    assert set(protos) == set(L.EXPORTS), set(protos) ^ set(L.EXPORTS)
+    for name, (ret, args) in protos.items():
+        res, argtypes = L.EXPORTS[name]
+        assert len(args) == len(argtypes), (name, args, argtypes)
+        for i, (decl, t) in enumerate(zip(args, argtypes)):
+            assert _c_kind(decl) == _ctype_kind(t), (name, i, decl, t)
+        want = "ptr" if "*" in ret else {"int": "i32", "size_t": "size"}[ret.replace("const", "").strip()]
+        assert _ctype_kind(res) == want, (name, ret, res)
+
+
 def test_dims_validation_no_gpu_needed():
     L, lib = _lib()
     ok = L.Dims(4, 24, 34, 13, 102, 0, 0, 0)

@@ -16,7 +16,7 @@ constexpr int FP = 16, PART = 2 * FP * FP + 2 * FP;   // GCN partial row: dW1 | 
 enum { T_C1W = 0, T_C1B, T_C2W, T_C2B, T_WIH, T_WHH, T_BIH, T_BHH };
 
 template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
-__device__ __forceinline__ void emit(const FinishArgs& a, int t, int idx, int row, int col, float gval, bool write_g,
+__device__ __forceinline__ void emit(const FinishArgs& a, int t, int64_t idx, int row, int col, float gval, bool write_g,
                                      bool& bad_g, bool& bad_w) {
   bad_g |= !(__builtin_fabsf(gval) <= 3.0e38f);                       // inf / NaN in a final gradient
   if (write_g) a.g[t][idx] = gval;
@@ -30,7 +30,7 @@ __device__ __forceinline__ void emit(const FinishArgs& a, int t, int idx, int ro
   const float w = __fsub_rn(a.p[t][idx], __fmul_rn(a.lr_over_bc1, __fdiv_rn(mi, denom)));
   a.p[t][idx] = w;
   if (a.prep_kind == 0 || (t != T_WIH && t != T_BIH)) return;
-  if (t == T_BIH) { col = a.I; row = idx; }                           // b_ih rides in column I of the forward image
+  if (t == T_BIH) { col = a.I; row = (int)idx; }                           // b_ih rides in column I of the forward image
   if (a.prep_kind == 1) {
     bad_w |= out_of_fp16_range(w);
     const _Float16 h = (_Float16)w, l = (_Float16)(w - (float)h);
@@ -89,7 +89,7 @@ __device__ __forceinline__ void seg_tn(const FinishArgs& a, const FinSeg& s, int
       else if (m >= s.rows1) continue;
     }
     if (m >= s.Mout) continue;
-    if (n < s.ncols) emit<ADAM>(a, tw, m * s.ncols + n, m, n, v[r], true, bad_g, bad_w);
+    if (n < s.ncols) emit<ADAM>(a, tw, (int64_t)m * s.ncols + n, m, n, v[r], true, bad_g, bad_w);
     else if (n == s.Nout - 1) emit<ADAM>(a, tb, m, m, 0, v[r], true, bad_g, bad_w);
   }
 }
@@ -124,7 +124,7 @@ __device__ __forceinline__ void seg_plain(const FinishArgs& a, const FinSeg& s, 
     else if (m >= s.rows1) return;
   }
   if (m >= s.Mout) return;
-  if (n < s.ncols) emit<ADAM>(a, tw, m * s.ncols + n, m, n, v, true, bad_g, bad_w);
+  if (n < s.ncols) emit<ADAM>(a, tw, (int64_t)m * s.ncols + n, m, n, v, true, bad_g, bad_w);
   else if (n == s.Nout - 1) emit<ADAM>(a, tb, m, m, 0, v, true, bad_g, bad_w);
 }
 
@@ -170,13 +170,14 @@ __device__ __forceinline__ void seg_conv(const FinishArgs& a, int blk, bool& bad
 // ---- tensors whose gradient is already final in g (after an all-reduce, or written directly by their kernel)
 template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
 __device__ __forceinline__ void seg_elem(const FinishArgs& a, int blk, bool& bad_g, bool& bad_w) {
-  int e = blk * 256 + threadIdx.x;
+  // 64-bit: the masked tensors TOGETHER may exceed 2^31 elements (configs[4]: W_ih 1.96e9 + W_hh 0.45e9)
+  int64_t e = (int64_t)blk * 256 + threadIdx.x;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     if (!((a.elem_mask >> t) & 1)) continue;
-    if (e < a.n[t]) {
+    if (e < (int64_t)a.n[t]) {
       const int ncols = t == T_WIH ? a.I : 1;
-      emit<ADAM>(a, t, e, e / ncols, e % ncols, a.g[t][e], false, bad_g, bad_w);
+      emit<ADAM>(a, t, e, (int)(e / ncols), (int)(e % ncols), a.g[t][e], false, bad_g, bad_w);
       return;
     }
     e -= a.n[t];
@@ -218,8 +219,11 @@ int launch_finish(FinishArgs a, hipStream_t st) {
   int64_t ne = 0;
   for (int t = 0; t < 8; ++t)
     if ((a.elem_mask >> t) & 1) ne += a.n[t];
-  a.elem_blocks = (int)((ne + 255) / 256);
-  const int grid = a.ih.nblocks + a.hh.nblocks + a.conv_blocks + a.elem_blocks;
+  const int64_t eb = (ne + 255) / 256;
+  const int64_t grid64 = (int64_t)a.ih.nblocks + a.hh.nblocks + a.conv_blocks + eb;
+  if (grid64 > 0x7fffffffll) return WGNN_ERR_SHAPE;                   // one launch's grid.x
+  a.elem_blocks = (int)eb;
+  const int grid = (int)grid64;
   if (grid < 1) return WGNN_OK;
   double by = 0.0;
   if (a.ih.kind) by += 4.0 * a.ih.splitk * a.ih.Mout * (double)a.ih.Nout;

@@ -71,6 +71,8 @@ class BucketExchange:
             t = torch.tensor([float(n_local)], dtype=torch.float64, device=self.bucket.device)
             dist.all_reduce(t, group=self.group)            # every step, every rank
             n_global = int(round(float(t.item())))
+        # n_local == 0 is legal (fewer windows than ranks): that rank contributes a zero bucket and still issues every
+        # collective (TrainStep._empty_shard_step); what is refused is refused identically on every rank or is a local bug
         if n_local < 0 or n_global < n_local or n_global < 1:
             raise RuntimeError("windgnn_amd: shard of %d windows in a global batch of %d" % (n_local, n_global))
         return grad_scale_for_shard(n_local, n_global)

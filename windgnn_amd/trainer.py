@@ -12,7 +12,11 @@ equal shards) so the summed bucket equals the gradient of the big-batch mean los
 loss on every rank.  The collectives themselves live in distributed.BucketExchange (every rank issues every collective on
 every step).
 
-The loss a step returns is a 0-dim VIEW of the bucket's header: read it (float(loss)) before the next step."""
+The loss a step returns is a 0-dim VIEW of the bucket's header (no clone launch per step): read it (float(loss)) or
+`.clone()` it before the next step -- a list of kept losses would all show the latest value.
+
+A rank whose shard is EMPTY (fewer windows than ranks) still issues every collective of the step: it contributes a zero
+bucket and runs the optimiser's launch on the summed gradient, so no rank is left waiting in an all-reduce."""
 from __future__ import annotations
 
 import torch
@@ -82,11 +86,42 @@ class TrainStep:
         self._prepared_version = self._param_version()
 
     def _adam(self):
-        return dict(exp_avg=self.m_views, exp_avg_sq=self.v_views, step=self.steps, lr=self.lr, beta1=self.betas[0],
+        # the step being taken: self.steps counts COMPLETED steps (a step that raises does not advance Adam's bias correction)
+        return dict(exp_avg=self.m_views, exp_avg_sq=self.v_views, step=self.steps + 1, lr=self.lr, beta1=self.betas[0],
                     beta2=self.betas[1], eps=self.eps)
 
+    def _empty_shard_step(self, A, X, n_global):
+        """This rank has no windows in this step: zero bucket, the same collectives as every other rank, the optimiser's
+        launch(es) on the summed gradient.  Returns (big-batch mean loss, empty Y)."""
+        if not self.collective:
+            raise RuntimeError("windgnn_amd: TrainStep.step needs at least one window (got a batch of %s)" % (tuple(X.shape),))
+        from .functional import _IO_OF, _adj
+        _, T, S, F = X.shape
+        _, fmt, nnz = _adj(A, S)
+        H = self.p_views[5].shape[1]
+        d = _lib.Dims(1, T, S, F, H, self.model.math, fmt, nnz, _IO_OF[X.dtype])    # sizes the finish launch (B-independent)
+        if self._prepared_version != self._param_version():
+            self._images(d)
+        pre = self._prepared
+        gs = self.exchange.shard_weight(0, n_global)                   # 0.0; the count collective, if any, is issued
+        self._gbuf.zero_()
+        if not self.overlap_collectives:
+            self.exchange.all_reduce_all(gs)
+            finish_step(d, self.p_views, self.g_views, 0, self._adam(), pre, self.device)
+        else:
+            work = self.exchange.start_gru()
+            wconv = self.exchange.start_conv(gs)
+            work.wait()
+            adam = self._adam()
+            finish_step(d, self.p_views, self.g_views, _lib.FINISH_ADAM_GRU, adam, pre, self.device)
+            wconv.wait()
+            finish_step(d, self.p_views, self.g_views, _lib.FINISH_ADAM_CONV, adam, pre, self.device)
+        self.steps += 1
+        return self._loss, torch.empty(0, T, H, dtype=X.dtype, device=X.device)
+
     def forward_backward(self, A, X, L):
-        """src/main.py:66,72,79: returns (loss, Y); gradients land in the flat bucket (no optimiser step)."""
+        """src/main.py:66,72,79: returns (loss, Y); gradients land in the flat bucket (no optimiser step).  `loss` is a
+        view of the bucket's header word (see the module docstring)."""
         X, L = X.contiguous(), L.contiguous()
         Y, stash, d = self._forward(A, X, L)
         loss = self._loss
@@ -107,10 +142,12 @@ class TrainStep:
         """One optimiser step on this rank's windows (src/main.py:66-80).  `n_global`: windows of ALL ranks in this step,
         when the caller knows it (a fixed global batch); None = the exchange all-reduces the count on every step (a host
         sync).  Launch-sized tail: ONE wgnn_finish (reduce the deferred partial sums + Adam + next step's W_ih images);
-        with a process group three of them around the two all-reduces."""
+        with a process group two of them around the one all-reduce.  The returned loss is a VIEW of the gradient bucket's
+        header word, overwritten by the next step (module docstring): float() or .clone() it to keep it."""
         X, L = X.contiguous(), L.contiguous()   # a strided batch slice is copied here, never read as if dense
         DEFER = _lib.BWD_DEFER
-        self.steps += 1
+        if X.shape[0] == 0:
+            return self._empty_shard_step(A, X, n_global)
         loss = self._loss
         if self.collective and not self.overlap_collectives:
             # the single-rank schedule, with ONE all-reduce of [loss | conv | GRU gradients] between the reduce-only finish and
@@ -154,6 +191,7 @@ class TrainStep:
                 gcn_gru_backward_mse_raw(d, A, X, self.p_views, Y, L, stash, self.g_views, loss, 1.0, part=part | DEFER,
                                          prepared=pre)
             finish_step(d, self.p_views, self.g_views, 6, self._adam(), pre, self.device)              # :79 tail + :80
+        self.steps += 1                         # only a step whose launches were all accepted counts
         if self.check_every and self.model.math != _lib.MATH_F32 and self.steps % self.check_every == 0:
             self.check()
         return loss, Y
