@@ -1218,7 +1218,8 @@ def test_finish_elementwise_adam_covers_more_than_2_31_elements():
     for k, pv, mv in zip(PARAM_KEYS, views[0], views[2]):
         lo, hi = float(pv.min()), float(pv.max())
         assert abs(lo - want) <= 1e-9 and abs(hi - want) <= 1e-9, (k, lo, hi)
-        assert float(mv.min()) == float(mv.max()) == float(torch.tensor(0.1, dtype=torch.float32)), k
+        m1 = float(torch.tensor(1.0) - torch.tensor(0.9))               # (1 - beta1) * g in fp32 = 0.100000024
+        assert float(mv.min()) == float(mv.max()) == m1, (k, float(mv.min()), float(mv.max()))
     del bufs, views
     torch.cuda.empty_cache()
 
@@ -1382,3 +1383,41 @@ def test_csr_adjacency_one_pass_fp16_mode(S, T, B, H, k):
 
 
 
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16x3g", "f16"])
+@pytest.mark.parametrize("S,T,B,H", [(34, 24, 256, 102), (34, 24, 37, 102), (7, 12, 32, 21), (5, 3, 17, 9), (16, 4, 16, 48),
+                                     (33, 1, 19, 100), (2, 7, 33, 6), (40, 3, 50, 120), (34, 5, 1, 102), (34, 24, 300, 127)])
+def test_fused_forward_front_end_is_bitwise_the_unfused_launches(S, T, B, H, math, monkeypatch):
+    """gcngi_fwd_kernel (GCN layers + input projection in one persistent kernel, g handed over through LDS)
+    against gcnx_fwd_kernel -> pgemm_nt_kernel (WGNN_FUSED_FWD=0): the same products in the same order, so Y, the loss and
+    all 8 gradients (the stash the fused kernel leaves: g's hi plane, + lo in strict f16x3) must agree BIT FOR BIT -- with
+    ragged B*T (not a multiple of the 32 / 64-row tile), odd S*13, every row-tile count that fits LDS, 16-bit I/O, with and
+    without a stash, and through wgnn_fwd_last."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd.data import forward_last
+    from windgnn_amd.functional import gcn_gru_forward_raw
+    dev = _dev()
+    g = torch.Generator().manual_seed(31 * S + B)
+    A = (torch.rand(S, S, generator=g) / S + 0.01).to(dev)
+    X = torch.rand(B, T, S, 13, generator=g).to(dev)
+    L = torch.rand(B, T, H, generator=g).to(dev)
+    p = orc.init_params(S, 13, H, seed=S + H)
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("WGNN_FUSED_FWD", fused)
+        model = _model_from(p, S, H, math)
+        out, loss, grads = _run_step(model, A, X, L)
+        with torch.no_grad():
+            y_inf = model(A, X).cpu()                                           # no stash: the fused kernel writes no g at all
+        params = [q.detach() for q in model.hot_path_parameters()]
+        y16 = gcn_gru_forward_raw(A, X.half(), params, model.math, want_stash=False)[0].cpu()   # fp16 X / Y
+        last = forward_last(model, A, X, 0.0, 87.5).cpu()
+        res[fused] = (out, loss, grads, y_inf, y16, last)
+    a, b = res["0"], res["1"]
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    assert torch.equal(a[3], b[3]) and torch.equal(a[3].reshape(a[0].shape), a[0])
+    assert torch.equal(a[4], b[4])
+    assert torch.equal(a[5], b[5])
+    for k in PARAM_KEYS:
+        assert torch.equal(a[2][k], b[2][k]), k

@@ -2,6 +2,7 @@
 // Orchestrates the kernels of gcn.hip / gemm.hip / gru.hip / train_ops.hip on the caller's stream,
 // inside caller-owned workspace and stash buffers.  No allocation, no host synchronisation.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -213,6 +214,12 @@ void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float
   }
 }
 
+// WGNN_FUSED_FWD (environment, read per call): "0" = the unfused GCN and projection launches; anything else / unset = fused
+bool fused_fwd_enabled() {
+  const char* e = getenv("WGNN_FUSED_FWD");
+  return !(e && e[0] == '0');
+}
+
 int check_dims(const wgnn_dims* d) {
   if (!d) return WGNN_ERR_NULL;
   if (d->B < 1 || d->T < 1 || d->S < 1 || d->H < 1) return WGNN_ERR_SHAPE;
@@ -308,6 +315,20 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
     if (!kept) {
       rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 0, p->b_ih, (int)L.I, img_f, L.np_g3, (int)L.Ip, status, st);
       if (rc != WGNN_OK) return rc;
+    }
+    // Fused front end (gcngi.hip): GCN layers + input projection in one persistent kernel, g through LDS.  The results are
+    // bit-identical to the two launches below (same products, same summation order); WGNN_FUSED_FWD=0 selects those.
+    if (!L.gen_gcn && !L.gen_gru && fused_fwd_enabled() && gcngi_supported(d->S, d->H, full)) {
+      const int planes = sf ? ((full && !L.dgi1) ? 2 : 1) : 0;     // what the backward reads of g: hi (mask, one-pass dW_ih), + lo (strict)
+      rc = launch_gcngi_fwd((int)L.BT, d->S, A, X, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias,
+                            sf ? (void*)g : nullptr, (int)L.Ip, planes, img_f, L.np_g3, GI, (int)L.Gp, (int)L.G3, full, status,
+                            ws + L.ws_xtail_f, st);
+      if (rc != WGNN_OK) return rc;
+      if (last)
+        return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, last, nullptr, nullptr, full, status,
+                               nullptr, nullptr, 0, 1, y_mul, y_add, st);
+      return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, Y, gates, sf ? sf + L.st_yp : nullptr,
+                             full, status, sf ? labels : nullptr, sf ? sf + L.st_stats : nullptr, d->io, 0, 1.f, 0.f, st);
     }
     if (L.gen_gcn)    // CSR adjacency: fp32 SpMM layers, layer 2 writes the g planes
       rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, (const float*)X, p->conv1_weight, p->conv1_bias,

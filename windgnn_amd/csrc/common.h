@@ -154,6 +154,13 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
                      const float* W2, const void* g_planes, int ldg, const void* dg, int ld_dg /*row pitch of dg, elements*/,
                      bool dg16 /*dg is one fp16 plane*/, const float* scales, int scale_in, float* partial, bool x3,
                      void* xtail_scratch, hipStream_t st);
+// fused forward front end (gcngi.hip): both GCN layers + the GRU input projection, g handed over through LDS.
+// g_planes (nullable) / stash_planes: the backward's copy of g (0: none, 1: hi plane, 2: hi + lo); Bplanes: the stage-major
+// image of [W_ih | b_ih] (launch_split_weight2); GI: fp32 rows (x3) or ONE fp16 plane (one-pass mode), row pitch ldgi elements
+bool gcngi_supported(int S, int H, bool x3);
+int launch_gcngi_fwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
+                     const float* W2, const float* b2, void* g_planes, int ldg, int stash_planes, const void* Bplanes,
+                     int Np, void* GI, int ldgi, int N, bool x3, unsigned* status, void* xtail_scratch, hipStream_t st);
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
                          int Rp, int Cp, unsigned* status, hipStream_t st);

@@ -1,0 +1,445 @@
+// Fused forward front end: both GraphConvLayers AND the GRU input projection in ONE persistent kernel, the layer-2
+// output tile g handed from its producers to the projection through LDS.
+//
+// Reference: GCN_GRU.forward, src/step6_gcn_gru_combined_model.py:17-23 -- conv1 -> conv2 -> view -> the input half of
+// nn.GRU (gi = W_ih g_t + b_ih for every step of the window) is ONE expression there; the unfused path (gcnx_fwd_kernel ->
+// pgemm_nt_kernel) writes g as fp16 hi/lo planes (2 x 88 MB at B = 4096) and reads them back.
+//
+// One workgroup per CU, persistent over tiles of R rows (row = one (window, timestep) = one [S][13] tile of X, one
+// 442-long row of g, one row of GI).  Two kinds of waves:
+//   * NG "GCN" waves: the register-chained two-layer graph convolution of gcnx_fwd_kernel, one row at a time; the
+//     result goes into the g tile in LDS as fp16 hi (+ lo) rows in the layout the projection's A fragments are read in,
+//     and -- only when the caller keeps a stash for the backward -- out to HBM (the hi plane, plus the lo plane when the
+//     backward multiplies with it: strict f16x3).  Inference (no stash) writes no g at all.
+//   * NM "GEMM" waves: GI[R][3H] = [g | 1] [W_ih | b_ih]^T for the tile the GCN waves finished one step earlier: A
+//     fragments from the LDS tile, B fragments STRAIGHT FROM L2 INTO REGISTERS -- the prepared image of W_ih is
+//     stage-major ([K/32][rows][32] halfs), so the fragment of one 16-column tile and K step is 1 KB contiguous, one
+//     global_load_dwordx4 per lane, double-buffered in registers; no LDS ring, no barriers inside the K loop.  Each GEMM
+//     wave owns a slice of the 3H columns for ALL R rows (B is fetched once per tile and CU).
+// The g tile is double-buffered: while the GEMM waves multiply tile i the GCN waves produce tile i + 1; one workgroup
+// barrier per tile.  The GCN stage is bound by its chain of dependent products and the VALU, the projection by the
+// matrix pipe: as separate launches they add up (90 + 84 us at B = 4096, f16x3), as co-resident waves they overlap.
+#include "gcnx_dev.h"
+
+namespace {
+
+constexpr int GG_PAD = 16;                       // pad bytes behind each g row in LDS (conflict-free b128 fragment reads; dump slot)
+
+// bytes of dynamic LDS: A-matrix fragments | per-GCN-wave X staging | 2 g tiles of PL planes x R rows
+constexpr size_t gg_smem(int NT, int NG, int R, int PL, int Ip) {
+  return (size_t)2 * NT * ((NT + 1) / 2) * 64 * 16 + (size_t)NG * 16 * NT * XS * 4 + (size_t)2 * PL * R * (2 * Ip + GG_PAD);
+}
+
+template <int NT, bool X3, bool IO, int NG, int NM, int R>
+__global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
+    int ntiles, int S, const float* __restrict__ A, const void* __restrict__ X, const void* __restrict__ xtail, int io,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+    const float* __restrict__ b2, _Float16* __restrict__ ghi, _Float16* __restrict__ glo, int ldp, int stash_planes,
+    const _Float16* __restrict__ Bpl, size_t bplane, int Np, void* __restrict__ GIv, int ldgi, int N, unsigned* status) {
+  constexpr int KS = (NT + 1) / 2;
+  constexpr int SP = 16 * NT;
+  constexpr int NP = (SP * F13 / 2 + 63) / 64;
+  constexpr int NF = NT * KS;
+  constexpr int PL = X3 ? 2 : 1;
+  constexpr int RT = R / 16;
+  static_assert(R % 16 == 0, "the projection works on 16-row MFMA tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  h8* const sCA = (h8*)smem;                                              // [frag][hi|lo][lane]
+  float* const sx = (float*)(smem + (size_t)2 * NF * 64 * 16);            // per GCN wave: [SP][XS] fp32
+  char* const gt = smem + (size_t)2 * NF * 64 * 16 + (size_t)NG * SP * XS * 4;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int I = S * F13;
+  const int pitch = 2 * ldp + GG_PAD;                                     // bytes per g row in LDS
+  const int plane_b = R * pitch, buf_b = PL * plane_b;
+  // tiles of this workgroup: blockIdx.x, + gridDim.x, ...  (every wave of the block agrees on nit: the barrier count)
+  const int ntile_r = (ntiles + R - 1) / R;
+  const int nit = (int)blockIdx.x < ntile_r ? (ntile_r - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+
+  // ---- one-time set-up: A fragments, zeroed staging, the constant tail of every g row (1.0 at column I, zeros behind)
+  if (wave < NG) {
+    float* xb0 = sx + wave * SP * XS;
+    for (int i = lane; i < SP * XS; i += 64) xb0[i] = 0.f;                 // pads (f >= 13, s >= S) stay zero forever
+  }
+  if (wave == 0) {
+    Frag T[NT][KS];
+    build_A_frags<NT, KS, false, X3>(T, A, S, c, g);
+#pragma unroll
+    for (int mi = 0; mi < NT; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sCA[((mi * KS + ks) * 2 + 0) * 64 + lane] = T[mi][ks].hi;
+        sCA[((mi * KS + ks) * 2 + 1) * 64 + lane] = T[mi][ks].lo;
+      }
+  }
+  {
+    const int tail = ldp - I + GG_PAD / 2;                                // halfs behind the data of a row, pad included
+    for (int q = threadIdx.x; q < 2 * PL * R * tail; q += blockDim.x) {
+      const int row = q / tail, e = q % tail;                              // row runs over buffers x planes x rows
+      const bool hi_plane = (row / R) % PL == 0;
+      *(_Float16*)(gt + (size_t)row * pitch + 2 * (I + e)) = (_Float16)((e == 0 && hi_plane) ? 1.f : 0.f);
+    }
+  }
+  __syncthreads();
+  if (nit == 0) return;
+
+  if (wave < NG) {
+    // =============================== GCN waves: rows wave, wave + NG, ... of every tile ===============================
+    float chk = 0.f;                                     // range check: see gcnx_fwd_kernel
+    float* xb = sx + wave * SP * XS;
+    constexpr bool HALF = (NT & 1) != 0;
+    h4v ahh[HALF ? NT : 1], ahl[HALF ? NT : 1];
+    if constexpr (HALF) {
+#pragma unroll
+      for (int mi = 0; mi < NT; ++mi) {
+        const h8 hh = sCA[((mi * KS + KS - 1) * 2 + 0) * 64 + lane], hl = sCA[((mi * KS + KS - 1) * 2 + 1) * 64 + lane];
+        ahh[mi] = __builtin_shufflevector(hh, hh, 0, 1, 2, 3);
+        ahl[mi] = __builtin_shufflevector(hl, hl, 0, 1, 2, 3);
+      }
+    }
+    auto ldA = [&](int mi, int ks) {
+      Frag f;
+      if (HALF && ks == KS - 1) {
+        f.hi = __builtin_shufflevector(ahh[HALF ? mi : 0], ahh[HALF ? mi : 0], 0, 1, 2, 3, 0, 1, 2, 3);
+        f.lo = __builtin_shufflevector(ahl[HALF ? mi : 0], ahl[HALF ? mi : 0], 0, 1, 2, 3, 0, 1, 2, 3);
+      } else {
+        f.hi = sCA[((mi * KS + ks) * 2 + 0) * 64 + lane];
+        f.lo = sCA[((mi * KS + ks) * 2 + 1) * 64 + lane];
+      }
+      return f;
+    };
+    Frag FW1, FW2;
+    float bb1[4], bb2[4];
+    {
+      float x1[8], x2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int f2 = 4 * g + j;
+        x1[j] = (j < 4 && f2 < F13 && c < F13) ? W1[f2 * F13 + c] : 0.f;
+        x2[j] = (j < 4 && f2 < F13 && c < F13) ? W2[f2 * F13 + c] : 0.f;
+      }
+      FW1 = split_vals<X3>(x1);
+      FW2 = split_vals<X3>(x2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 4 * g + r;
+        bb1[r] = f < F13 ? b1[f] : 0.f;
+        bb2[r] = f < F13 ? b2[f] : 0.f;
+      }
+    }
+    PairMap<NP> map;
+    map.init(lane, I, SP * XS - 1);
+    // byte offsets of this lane's output values inside a g row: value r of column tile n is g[s = 16n + c][f' = 4g + r];
+    // values past the tile (s >= S, f' >= 13) go to the row's pad (never read)
+    int go[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s = 16 * n + c, f = 4 * g + r;
+        go[n][r] = (s < S && f < F13) ? 2 * (s * F13 + f) : 2 * ldp;
+      }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias1 = {bb1[0], bb1[1], bb1[2], bb1[3]}, bias2 = {bb2[0], bb2[1], bb2[2], bb2[3]};
+    constexpr int RW = (R + NG - 1) / NG;                                  // rows per wave and tile (the last may be off)
+    const int nrw = (wave + NG * (RW - 1) < R) ? RW : RW - 1;              // wave-uniform
+    const int total = nit * nrw;
+    // idx-th row of this wave -> global row (tile of X), clamped into the tensor (rows past it are recomputed copies of
+    // the last row: their g rows are never stored and the projection's rows past the tensor are never written)
+    auto row_of = [&](int idx, int& tp, int& r) {
+      tp = idx / nrw;
+      r = wave + NG * (idx % nrw);
+      return ((int)blockIdx.x + tp * (int)gridDim.x) * R + r;
+    };
+    f32x2 xr[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) xr[k] = f32x2{0.f, 0.f};
+    auto stage_x = [&]() {
+      if (IO && io == 1) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const f32x2 v = io_pair(xr[k], 1);
+          xb[map.o0[k]] = v[0];
+          xb[map.o1[k]] = v[1];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const f32x2 v = IO ? io_pair(xr[k], 2) : xr[k];
+          xb[map.o0[k]] = v[0];
+          xb[map.o1[k]] = v[1];
+        }
+      }
+    };
+    if (total > 0) {
+      int tp, r;
+      const int t = min(row_of(0, tp, r), ntiles - 1);
+      XLOAD(t);
+      stage_x();
+    }
+    for (int idx = 0; idx < total; ++idx) {
+      asm volatile("" ::: "memory");                    // keep the A-fragment reads in LDS (no hoisting into VGPRs)
+      int tp, r;
+      const int t_raw = row_of(idx, tp, r);
+      wave_lds_fence();                                 // this row's X is staged
+      const bool more = idx + 1 < total;
+      if (more) {
+        int tp2, r2;
+        const int t2 = min(row_of(idx + 1, tp2, r2), ntiles - 1);
+        XLOAD(t2);                                      // prefetch the next row's X under this row's math
+      }
+      f32x4 U[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) U[i] = mfma3h<X3>(xfrag_nat<X3>(xb, i, c, g), FW1, zero4);
+      Frag UF[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) UF[ks] = (2 * ks + 1 < NT) ? frag_of<X3>(U[2 * ks], U[2 * ks + 1]) : frag_half<X3>(U[2 * ks]);
+      f32x4 Ht[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 acc = bias1;
+        f32x4 acc16 = zero4;                       // MIXED_FORMS (gcnx_dev.h): the K = 16 step has its own accumulator
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (2 * ks + 1 < NT) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
+          else if (X3) acc16 = mfma3h<X3>(UF[ks], ldA(n, ks), acc16);
+          else acc = mfma3h<X3>(UF[ks], ldA(n, ks), acc);
+        }
+        if (X3 && (NT & 1)) acc += acc16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Ht[n][q] = relu_nan(acc[q]);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) U[i] = mfma3h<X3>(frag_half<X3>(Ht[i]), FW2, zero4);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) UF[ks] = (2 * ks + 1 < NT) ? frag_of<X3>(U[2 * ks], U[2 * ks + 1]) : frag_half<X3>(U[2 * ks]);
+      char* const grow = gt + (tp & 1) * buf_b + r * pitch;                // this row of the tile being produced
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 acc = bias2;
+        f32x4 acc16 = zero4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (2 * ks + 1 < NT) acc = mfma3<X3>(UF[ks], ldA(n, ks), acc);
+          else if (X3) acc16 = mfma3h<X3>(UF[ks], ldA(n, ks), acc16);
+          else acc = mfma3h<X3>(UF[ks], ldA(n, ks), acc);
+        }
+        if (X3 && (NT & 1)) acc += acc16;
+        // g^T[f' = 4g..4g+3][s = 16n + c] -> halfs of the row, station-major (s * 13 + f'), hi (and lo) plane
+        unsigned h01, l01, h23, l23;
+        float d0, d1, d2, d3;
+        split2t(relu_nan(acc[0]), relu_nan(acc[1]), h01, l01, d0, d1);
+        split2t(relu_nan(acc[2]), relu_nan(acc[3]), h23, l23, d2, d3);
+        chk = __builtin_fmaf(d0, 0.f, __builtin_fmaf(d1, 0.f, chk));
+        chk = __builtin_fmaf(d2, 0.f, __builtin_fmaf(d3, 0.f, chk));
+        const h2 H01 = __builtin_bit_cast(h2, h01), H23 = __builtin_bit_cast(h2, h23);
+        *(_Float16*)(grow + go[n][0]) = H01[0];
+        *(_Float16*)(grow + go[n][1]) = H01[1];
+        *(_Float16*)(grow + go[n][2]) = H23[0];
+        *(_Float16*)(grow + go[n][3]) = H23[1];
+        if (X3) {
+          const h2 L01 = __builtin_bit_cast(h2, l01), L23 = __builtin_bit_cast(h2, l23);
+          *(_Float16*)(grow + plane_b + go[n][0]) = L01[0];
+          *(_Float16*)(grow + plane_b + go[n][1]) = L01[1];
+          *(_Float16*)(grow + plane_b + go[n][2]) = L23[0];
+          *(_Float16*)(grow + plane_b + go[n][3]) = L23[1];
+        }
+      }
+      wave_lds_fence();                                  // the row is complete in LDS (this wave's own writes)
+      if (more) stage_x();                               // xb was last read by the U1 products above
+      if (stash_planes > 0 && t_raw < ntiles) {          // the backward's copy of g: coalesced dwords out of the LDS row
+        unsigned* dh = (unsigned*)(ghi + (size_t)t_raw * ldp);
+        unsigned* dl = (unsigned*)(glo + (size_t)t_raw * ldp);
+        const int nd = ldp / 2;
+        for (int p = lane; p < nd; p += 64) {
+          dh[p] = *(const unsigned*)(grow + 4 * p);
+          if (X3 && stash_planes > 1) dl[p] = *(const unsigned*)(grow + plane_b + 4 * p);
+        }
+      }
+      if (idx % nrw == nrw - 1) {                        // last row of tile tp: hand the tile over
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    static_assert(R >= NG, "every GCN wave has at least one row per tile (it owes one barrier per tile)");
+    report_status(status, chk != chk, WGNN_STATUS_ACT_RANGE);
+    return;
+  }
+
+  // =============================== GEMM waves: a slice of the 3H columns, all R rows ===============================
+  {
+    const int q = wave - NG;
+    const int ntn = (N + 15) / 16;                                          // 16-column tiles of GI
+    const int base = ntn / NM, extra = ntn % NM;
+    const int nct = base + (q < extra ? 1 : 0);                             // wave-uniform
+    const int ct0 = q * base + (q < extra ? q : extra);
+    const int nk = ldp / 32;
+    const int r16 = lane & 15, c4 = lane >> 4;
+    const _Float16* const bb = Bpl + ((size_t)16 * ct0 + r16) * 32 + 8 * c4;   // + plane * bplane + (kt * Np + 16 j) * 32
+    const size_t kstride = (size_t)Np * 32;
+    constexpr int CTMAX = 3;
+    auto consume = [&](auto ctc, const char* buf, int m0) {
+      constexpr int CT = decltype(ctc)::value;
+      f32x4 acc[RT][CT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      h8 b0h[CT], b0l[CT], b1h[CT], b1l[CT];
+      auto loadB = [&](h8 (&bh)[CT], h8 (&bl)[CT], int kt) {
+        const _Float16* p = bb + kt * kstride;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          bh[j] = *(const h8*)(p + j * 512);
+          if (X3) bl[j] = *(const h8*)(p + bplane + j * 512);
+        }
+      };
+      auto mult = [&](const h8 (&bh)[CT], const h8 (&bl)[CT], int kt) {
+        const char* a = buf + r16 * pitch + kt * 64 + c4 * 16;
+        h8 ah[RT], al[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          ah[i] = *(const h8*)(a + i * 16 * pitch);
+          if (X3) al[i] = *(const h8*)(a + plane_b + i * 16 * pitch);
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          if (X3) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+              acc[i][j] = mfma_x(al[i], bh[j], acc[i][j]);
+              acc[i][j] = mfma_x(ah[i], bl[j], acc[i][j]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < RT; ++i) acc[i][j] = mfma_x(ah[i], bh[j], acc[i][j]);
+        }
+      };
+      loadB(b0h, b0l, 0);
+      int kt = 0;
+      for (; kt + 1 < nk; kt += 2) {
+        loadB(b1h, b1l, kt + 1);
+        mult(b0h, b0l, kt);
+        if (kt + 2 < nk) loadB(b0h, b0l, kt + 2);
+        mult(b1h, b1l, kt + 1);
+      }
+      if (kt < nk) mult(b0h, b0l, kt);
+      // ---- epilogue: GI rows m0 + 16 i + 4 c4 + r, columns 16 (ct0 + j) + r16
+      if (X3) {
+        float* GI = (float*)GIv;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const int col = 16 * (ct0 + j) + r16;
+          if (col >= N) continue;
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = m0 + 16 * i + 4 * c4 + r;
+              if (row < ntiles) GI[(size_t)row * ldgi + col] = acc[i][j][r];
+            }
+        }
+      } else {   // one-pass fp16 mode: GI is ONE fp16 plane; neighbouring lanes exchange values and store packed column pairs
+        _Float16* Ch = (_Float16*)GIv;
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const int col = 16 * (ct0 + j) + r16, colp = col & ~1;
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            const f32x4 v = acc[i][j];
+            const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];            // what the partner needs from me
+            const float k0 = odd ? v[2] : v[0], k1 = odd ? v[3] : v[1];            // what I keep
+            const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
+            const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+            const f32x2 a0 = {odd ? x0 : k0, odd ? k0 : x0}, a1 = {odd ? x1 : k1, odd ? k1 : x1};
+            const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a0, h2));
+            const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(a1, h2));
+            const int row = m0 + 16 * i + 4 * c4 + (odd ? 2 : 0);
+            if (colp < N) {
+              if (row < ntiles) *(unsigned*)(Ch + (size_t)row * ldgi + colp) = p0;
+              if (row + 1 < ntiles) *(unsigned*)(Ch + (size_t)(row + 1) * ldgi + colp) = p1;
+            }
+          }
+        }
+      }
+    };
+    for (int it = 0; it < nit; ++it) {
+      __builtin_amdgcn_s_barrier();                       // tile `it` is complete in LDS (the producers waited for their writes)
+      asm volatile("" ::: "memory");
+      const char* buf = gt + (it & 1) * buf_b;
+      const int m0 = ((int)blockIdx.x + it * (int)gridDim.x) * R;
+      if (nct == 3) consume(std::integral_constant<int, 3>{}, buf, m0);
+      else if (nct == 2) consume(std::integral_constant<int, 2>{}, buf, m0);
+      else if (nct == 1) consume(std::integral_constant<int, 1>{}, buf, m0);
+      static_assert(CTMAX == 3, "the dispatch above covers 1..3 column tiles per wave");
+    }
+  }
+}
+
+}  // namespace
+
+// Can the fused front end run this shape?  Dense adjacency (the caller checks), S <= 64, at most 3 column tiles per GEMM
+// wave (3H <= 16 * 3 * 8), and the two g tiles must fit the CU's 160 KB next to the A fragments and the X staging.
+static constexpr int GG_NG = 8, GG_NM = 8;
+static int gg_rows(bool x3) { return x3 ? 32 : 64; }
+bool gcngi_supported(int S, int H, bool x3) {
+  const int NT = (S + 15) / 16;
+  if (NT < 1 || NT > 4) return false;
+  if ((3 * H + 15) / 16 > 3 * GG_NM) return false;
+  const int Ip = (S * 13 + 1 + 31) / 32 * 32;
+  return gg_smem(NT, GG_NG, gg_rows(x3), x3 ? 2 : 1, Ip) <= (size_t)160 * 1024;
+}
+
+// ghi / glo: the stash planes of g (stash_planes = 0: none written; 1: hi; 2: hi + lo).  W_ih image: stage-major planes
+// [Kp / 32][Np][32] halfs, hi then lo (launch_split_weight2 / wgnn_prepare_weights), column I = b_ih.
+int launch_gcngi_fwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
+                     const float* W2, const float* b2, void* g_planes, int ldg, int stash_planes, const void* Bplanes,
+                     int Np, void* GI, int ldgi, int N, bool x3, unsigned* status, void* xtail_scratch, hipStream_t st) {
+  const int NTs = (S + 15) / 16;
+  const size_t I = (size_t)S * 13, es = io ? 2 : 4;
+  const void* xt = nullptr;
+  if (I & 1) {                                         // odd tile length: private copy of X's last tile (XLOAD)
+    if (!xtail_scratch) return WGNN_ERR_NULL;
+    if (hipMemcpyAsync(xtail_scratch, (const char*)X + (size_t)(ntiles - 1) * I * es, I * es, hipMemcpyDeviceToDevice, st) !=
+        hipSuccess)
+      return WGNN_ERR_HIP;
+    xt = xtail_scratch;
+  }
+  _Float16* ghi = (_Float16*)g_planes;
+  _Float16* glo = ghi ? ghi + (size_t)ntiles * ldg : nullptr;
+  if (!ghi) stash_planes = 0;
+  const int R = gg_rows(x3);
+  const int ntile_r = cdiv_i(ntiles, R);
+  const int grid = ntile_r < 256 ? ntile_r : 256;
+  const size_t bplane = (size_t)Np * ldg;
+  const size_t smem = gg_smem(NTs, GG_NG, R, x3 ? 2 : 1, ldg);
+  const double fl = (double)ntiles * (2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13) + 2.0 * (double)N * ldg);
+  const double by = (double)ntiles * (S * 13 * (io ? 2.0 : 4.0) + stash_planes * 2.0 * ldg + (x3 ? 4.0 : 2.0) * N);
+#define GG_GO(NT, X3V, IOV, RV, NAME)                                                                                  \
+  do {                                                                                                                 \
+    static std::atomic<unsigned long long> done_{0};                                                                   \
+    if (ensure_dyn_smem((const void*)gcngi_fwd_kernel<NT, X3V, IOV, GG_NG, GG_NM, RV>, smem, done_) != WGNN_OK)        \
+      return WGNN_ERR_HIP;                                                                                             \
+    PROF_LAUNCH(NAME, fl, by, st,                                                                                      \
+                hipLaunchKernelGGL((gcngi_fwd_kernel<NT, X3V, IOV, GG_NG, GG_NM, RV>), dim3(grid),                     \
+                                   dim3(64 * (GG_NG + GG_NM)), smem, st, ntiles, S, A, X, xt, io, W1, b1, W2, b2, ghi, \
+                                   glo, ldg, stash_planes, (const _Float16*)Bplanes, bplane, Np, GI, ldgi, N, status)); \
+  } while (0)
+#define GG_CASE(NT)                                                                      \
+  if (x3 && !io) GG_GO(NT, true, false, 32, "gcngi_fwd_kernel<" #NT ">");                \
+  else if (x3) GG_GO(NT, true, true, 32, "gcngi_fwd_kernel<" #NT ">");                   \
+  else if (!io) GG_GO(NT, false, false, 64, "gcngi_fwd_kernel<" #NT ",f16>");            \
+  else GG_GO(NT, false, true, 64, "gcngi_fwd_kernel<" #NT ",f16>")
+  switch (NTs) {
+    case 1: GG_CASE(1); break;
+    case 2: GG_CASE(2); break;
+    case 3: GG_CASE(3); break;
+    case 4: GG_CASE(4); break;
+    default: return WGNN_ERR_UNSUPPORTED;
+  }
+#undef GG_CASE
+#undef GG_GO
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
