@@ -13,7 +13,7 @@ tr = TrainStep(m)
 A = adjacency_34().to(dev)
 X, L = make_inputs(4096, 0, dev, io=io)
 tr.step(A, X, L)
-for fused in ("0", "1"):
+for fused in ("0", "2"):
     os.environ["WGNN_FUSED_FWD"] = fused
     for what in ("forward only (no stash)", "training step"):
         fn = (lambda: gcn_gru_forward_raw(A, X, tr.p_views, m.math, want_stash=False, prepared=tr._prepared)) \

@@ -1,5 +1,6 @@
 """r4 probe: per-tile latency of gcnx_fwd with a lighter memory skeleton / fewer resident waves (what a fused GCN -> GI kernel
-would give its GCN waves).  Knobs are env vars read by launch_gcnx2_fwd (experiment build only).
+would give its GCN waves).  The knobs (WGNN_EXP_FWD_GRID / _LDS / _STORE) existed in launch_gcnx2_fwd only in the experiment
+build of commit "gcngi.hip: fused GCN -> input-projection forward" (r4); the results are profiles/r4_probe_gcn_fwd_latency.txt.
     MATH=f16x3|f16 python tools/exp/gcn_fwd_latency.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -214,10 +214,16 @@ void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float
   }
 }
 
-// WGNN_FUSED_FWD (environment, read per call): "0" = the unfused GCN and projection launches; anything else / unset = fused
-bool fused_fwd_enabled() {
+// WGNN_FUSED_FWD (environment, read per call): which forwards run the fused GCN + projection kernel (gcngi.hip).
+//   unset / "1"  forwards WITHOUT a stash (inference: wgnn_fwd(stash = NULL), wgnn_fwd_last) -- where it measured faster
+//                (B = 4096: f16x3 238 -> 215 us, f16 + bf16 I/O 149 -> 139 us; no g plane reaches HBM);
+//   "2"          every forward it supports, training too (there the stash copy of g makes it slower: 742 -> 770 us per step
+//                in f16x3, 522 -> 527 in f16: DESIGN.md section 5, round 4);
+//   "0"          never.  The results are bit-identical either way (tests/test_gpu_parity.py).
+int fused_fwd_mode() {
   const char* e = getenv("WGNN_FUSED_FWD");
-  return !(e && e[0] == '0');
+  if (!e || !e[0]) return 1;
+  return e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
 }
 
 int check_dims(const wgnn_dims* d) {
@@ -317,8 +323,9 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
       if (rc != WGNN_OK) return rc;
     }
     // Fused front end (gcngi.hip): GCN layers + input projection in one persistent kernel, g through LDS.  The results are
-    // bit-identical to the two launches below (same products, same summation order); WGNN_FUSED_FWD=0 selects those.
-    if (!L.gen_gcn && !L.gen_gru && fused_fwd_enabled() && gcngi_supported(d->S, d->H, full)) {
+    // bit-identical to the two launches below (same products, same summation order); WGNN_FUSED_FWD selects (above).
+    const int fmode = fused_fwd_mode();
+    if (!L.gen_gcn && !L.gen_gru && (fmode == 2 || (fmode == 1 && !sf)) && gcngi_supported(d->S, d->H, full)) {
       const int planes = sf ? ((full && !L.dgi1) ? 2 : 1) : 0;     // what the backward reads of g: hi (mask, one-pass dW_ih), + lo (strict)
       rc = launch_gcngi_fwd((int)L.BT, d->S, A, X, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias,
                             sf ? (void*)g : nullptr, (int)L.Ip, planes, img_f, L.np_g3, GI, (int)L.Gp, (int)L.G3, full, status,

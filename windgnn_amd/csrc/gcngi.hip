@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
     for (int idx = 0; idx < total; ++idx) {
       asm volatile("" ::: "memory");                    // keep the A-fragment reads in LDS (no hoisting into VGPRs)
       int tp, r;
-      const int t_raw = row_of(idx, tp, r);
+      row_of(idx, tp, r);
       wave_lds_fence();                                 // this row's X is staged
       const bool more = idx + 1 < total;
       if (more) {
@@ -247,15 +247,6 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
       }
       wave_lds_fence();                                  // the row is complete in LDS (this wave's own writes)
       if (more) stage_x();                               // xb was last read by the U1 products above
-      if (stash_planes > 0 && t_raw < ntiles) {          // the backward's copy of g: coalesced dwords out of the LDS row
-        unsigned* dh = (unsigned*)(ghi + (size_t)t_raw * ldp);
-        unsigned* dl = (unsigned*)(glo + (size_t)t_raw * ldp);
-        const int nd = ldp / 2;
-        for (int p = lane; p < nd; p += 64) {
-          dh[p] = *(const unsigned*)(grow + 4 * p);
-          if (X3 && stash_planes > 1) dl[p] = *(const unsigned*)(grow + plane_b + 4 * p);
-        }
-      }
       if (idx % nrw == nrw - 1) {                        // last row of tile tp: hand the tile over
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -275,32 +266,46 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
     const int ct0 = q * base + (q < extra ? q : extra);
     const int nk = ldp / 32;
     const int r16 = lane & 15, c4 = lane >> 4;
-    const _Float16* const bb = Bpl + ((size_t)16 * ct0 + r16) * 32 + 8 * c4;   // + plane * bplane + (kt * Np + 16 j) * 32
-    const size_t kstride = (size_t)Np * 32;
-    constexpr int CTMAX = 3;
-    auto consume = [&](auto ctc, const char* buf, int m0) {
+    // B fragment (column tile j, K step kt, plane pl) = 1 KB contiguous at Bpl + pl * bplane + (kt * Np + 16 (ct0 + j)) * 32
+    // halfs: a per-lane byte offset (fixed) on top of a scalar base that advances with kt; j rides in the immediate offset
+    const size_t kstride_b = (size_t)Np * 64;                               // bytes per K step
+    auto consume = [&](auto ctc, const char* buf, int m0, int ctb) {
       constexpr int CT = decltype(ctc)::value;
+      const unsigned boff = (unsigned)((((16 * ctb + r16) * 32) + 8 * c4) * 2);   // this lane's bytes inside a stage
       f32x4 acc[RT][CT];
 #pragma unroll
       for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // The B stream is double-buffered in registers.  Left alone, the scheduler sinks the next stage's loads below the
+      // current stage's MFMAs (24 live VGPRs less) and the K step drains vmcnt to 0 before its last product: no load was
+      // ever in flight under the MFMAs.  A sched_barrier behind every issue() pins the loads in front of the products;
+      // the waits themselves are the compiler's (in-order vmcnt: "all but the stage just requested").  (Hand-placed
+      // s_waitcnt around asm loads is NOT an option: the register allocator copies the destination registers -- loop
+      // phis -- between the asm load and the wait, i.e. it reads them before the data is there.)
       h8 b0h[CT], b0l[CT], b1h[CT], b1l[CT];
-      auto loadB = [&](h8 (&bh)[CT], h8 (&bl)[CT], int kt) {
-        const _Float16* p = bb + kt * kstride;
+      auto issue = [&](h8 (&bh)[CT], h8 (&bl)[CT], int kt) {
+        const char* ph = (const char*)Bpl + (size_t)kt * kstride_b + boff;
+
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
-          bh[j] = *(const h8*)(p + j * 512);
-          if (X3) bl[j] = *(const h8*)(p + bplane + j * 512);
+          bh[j] = *(const h8*)(ph + j * 1024);
+          if (X3) bl[j] = *(const h8*)(ph + 2 * bplane + j * 1024);
         }
+        __builtin_amdgcn_sched_barrier(0);
       };
-      auto mult = [&](const h8 (&bh)[CT], const h8 (&bl)[CT], int kt) {
+      auto mult = [&](const h8 (&bh)[CT], const h8 (&bl)[CT], int kt, bool live) {
         const char* a = buf + r16 * pitch + kt * 64 + c4 * 16;
         h8 ah[RT], al[RT];
+        const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
           ah[i] = *(const h8*)(a + i * 16 * pitch);
           if (X3) al[i] = *(const h8*)(a + plane_b + i * 16 * pitch);
+          if (!live) {                           // the step past an odd K (wave-uniform): zero A, the products stay in the stream
+            ah[i] = zero8;
+            if (X3) al[i] = zero8;
+          }
         }
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
@@ -315,28 +320,38 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
           for (int i = 0; i < RT; ++i) acc[i][j] = mfma_x(ah[i], bh[j], acc[i][j]);
         }
       };
-      loadB(b0h, b0l, 0);
-      int kt = 0;
-      for (; kt + 1 < nk; kt += 2) {
-        loadB(b1h, b1l, kt + 1);
-        mult(b0h, b0l, kt);
-        if (kt + 2 < nk) loadB(b0h, b0l, kt + 2);
-        mult(b1h, b1l, kt + 1);
+      // (every issue() is unconditional -- past the end it re-requests the last stage -- because a load on only one of two
+      // merging paths makes the compiler's wait the conservative vmcnt(0) on both)
+      // Both products of the unrolled pair are unconditional too (an odd K multiplies its clamped extra stage by zeros): a
+      // conditional second product had its stage's loads sunk into the branch, next to their use.
+      issue(b0h, b0l, 0);
+      for (int kt = 0; kt < nk; kt += 2) {
+        issue(b1h, b1l, min(kt + 1, nk - 1));
+        mult(b0h, b0l, kt, true);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(b0h, b0l, min(kt + 2, nk - 1));
+        mult(b1h, b1l, min(kt + 1, nk - 1), kt + 1 < nk);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (kt < nk) mult(b0h, b0l, kt);
-      // ---- epilogue: GI rows m0 + 16 i + 4 c4 + r, columns 16 (ct0 + j) + r16
+      // ---- epilogue: GI rows m0 + 16 i + 4 c4 + r, columns 16 (ct0 + j) + r16.  A tile inside the tensor (all but the
+      // last one) stores without per-row guards; columns >= N (only the last wave's last tile can have them) are skipped
+      const bool full = m0 + R <= ntiles;                                   // wave-uniform
       if (X3) {
         float* GI = (float*)GIv;
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
-          const int col = 16 * (ct0 + j) + r16;
-          if (col >= N) continue;
+          const int col = 16 * (ctb + j) + r16;
+          float* dst = GI + (size_t)(m0 + 4 * c4) * ldgi + (col < N ? col : 0);
 #pragma unroll
           for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int row = m0 + 16 * i + 4 * c4 + r;
-              if (row < ntiles) GI[(size_t)row * ldgi + col] = acc[i][j][r];
+              const int lr = 16 * i + r;
+              if (full) {
+                if (col < N) dst[(size_t)lr * ldgi] = acc[i][j][r];
+              } else if (col < N && m0 + 4 * c4 + lr < ntiles) {
+                dst[(size_t)lr * ldgi] = acc[i][j][r];
+              }
             }
         }
       } else {   // one-pass fp16 mode: GI is ONE fp16 plane; neighbouring lanes exchange values and store packed column pairs
@@ -344,7 +359,7 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
         const bool odd = lane & 1;
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
-          const int col = 16 * (ct0 + j) + r16, colp = col & ~1;
+          const int col = 16 * (ctb + j) + r16, colp = col & ~1;
 #pragma unroll
           for (int i = 0; i < RT; ++i) {
             const f32x4 v = acc[i][j];
@@ -357,8 +372,8 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
             const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(a1, h2));
             const int row = m0 + 16 * i + 4 * c4 + (odd ? 2 : 0);
             if (colp < N) {
-              if (row < ntiles) *(unsigned*)(Ch + (size_t)row * ldgi + colp) = p0;
-              if (row + 1 < ntiles) *(unsigned*)(Ch + (size_t)(row + 1) * ldgi + colp) = p1;
+              if (full || row < ntiles) *(unsigned*)(Ch + (size_t)row * ldgi + colp) = p0;
+              if (full || row + 1 < ntiles) *(unsigned*)(Ch + (size_t)(row + 1) * ldgi + colp) = p1;
             }
           }
         }
@@ -369,26 +384,50 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
       asm volatile("" ::: "memory");
       const char* buf = gt + (it & 1) * buf_b;
       const int m0 = ((int)blockIdx.x + it * (int)gridDim.x) * R;
-      if (nct == 3) consume(std::integral_constant<int, 3>{}, buf, m0);
-      else if (nct == 2) consume(std::integral_constant<int, 2>{}, buf, m0);
-      else if (nct == 1) consume(std::integral_constant<int, 1>{}, buf, m0);
-      static_assert(CTMAX == 3, "the dispatch above covers 1..3 column tiles per wave");
+      // at most 3 column tiles per pass over K (registers: RT x 3 accumulator tiles + two stages of 3 x PL fragments);
+      // a wave with more (4 GEMM waves: 5 of the 20 tiles of 3H = 306) takes them in two passes -- B is still fetched once
+      for (int done = 0; done < nct; done += 3) {
+        const int nn = nct - done < 3 ? nct - done : 3;
+        if (nn == 3) consume(std::integral_constant<int, 3>{}, buf, m0, ct0 + done);
+        else if (nn == 2) consume(std::integral_constant<int, 2>{}, buf, m0, ct0 + done);
+        else consume(std::integral_constant<int, 1>{}, buf, m0, ct0 + done);
+      }
+      // the backward's copy of g (stash): the finished tile leaves LDS as 16-byte pieces, rows q, q + NM, ... per wave --
+      // on the GEMM waves, which have slack, not in the GCN waves' dependent chain (there it cost 26-31 us per launch)
+      if (stash_planes > 0) {
+        const int cpr = ldp / 8;                                            // 16-byte pieces per row (ldp is a multiple of 32)
+        for (int row = q; row < R && m0 + row < ntiles; row += NM) {
+          for (int ch = lane; ch < cpr; ch += 64) {
+            typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+            const u32x4v vh = *(const u32x4v*)(buf + row * pitch + 16 * ch);
+            *(u32x4v*)((char*)ghi + ((size_t)(m0 + row) * ldp) * 2 + 16 * ch) = vh;
+            if (X3 && stash_planes > 1) {
+              const u32x4v vl = *(const u32x4v*)(buf + plane_b + row * pitch + 16 * ch);
+              *(u32x4v*)((char*)glo + ((size_t)(m0 + row) * ldp) * 2 + 16 * ch) = vl;
+            }
+          }
+        }
+      }
     }
   }
 }
 
 }  // namespace
 
-// Can the fused front end run this shape?  Dense adjacency (the caller checks), S <= 64, at most 3 column tiles per GEMM
-// wave (3H <= 16 * 3 * 8), and the two g tiles must fit the CU's 160 KB next to the A fragments and the X staging.
-static constexpr int GG_NG = 8, GG_NM = 8;
-static int gg_rows(bool x3) { return x3 ? 32 : 64; }
+// Configuration per math mode (waves per role, rows per tile): split fp16 keeps hi + lo rows in LDS (32-row tiles, 8 + 8 waves
+// at 128 VGPRs); the one-pass mode's rows are half as large and its projection a third of the MFMA work, so it runs 12 GCN
+// waves beside 4 GEMM waves on 48-row tiles.
+struct GgCfg { int ng, nm, rows; };
+static GgCfg gg_cfg(bool x3) { return x3 ? GgCfg{8, 8, 32} : GgCfg{12, 4, 48}; }
+// Can the fused front end run this shape?  Dense adjacency (the caller checks), S <= 64, 3H <= 384 (the GEMM waves' column
+// split), and the two g tiles must fit the CU's 160 KB next to the A fragments and the X staging.
 bool gcngi_supported(int S, int H, bool x3) {
   const int NT = (S + 15) / 16;
   if (NT < 1 || NT > 4) return false;
-  if ((3 * H + 15) / 16 > 3 * GG_NM) return false;
+  if (3 * H > 384) return false;
   const int Ip = (S * 13 + 1 + 31) / 32 * 32;
-  return gg_smem(NT, GG_NG, gg_rows(x3), x3 ? 2 : 1, Ip) <= (size_t)160 * 1024;
+  const GgCfg c = gg_cfg(x3);
+  return gg_smem(NT, c.ng, c.rows, x3 ? 2 : 1, Ip) <= (size_t)160 * 1024;
 }
 
 // ghi / glo: the stash planes of g (stash_planes = 0: none written; 1: hi; 2: hi + lo).  W_ih image: stage-major planes
@@ -409,28 +448,29 @@ int launch_gcngi_fwd(int ntiles, int S, const float* A, const void* X, int io, c
   _Float16* ghi = (_Float16*)g_planes;
   _Float16* glo = ghi ? ghi + (size_t)ntiles * ldg : nullptr;
   if (!ghi) stash_planes = 0;
-  const int R = gg_rows(x3);
+  const GgCfg cfg = gg_cfg(x3);
+  const int R = cfg.rows;
   const int ntile_r = cdiv_i(ntiles, R);
   const int grid = ntile_r < 256 ? ntile_r : 256;
   const size_t bplane = (size_t)Np * ldg;
-  const size_t smem = gg_smem(NTs, GG_NG, R, x3 ? 2 : 1, ldg);
+  const size_t smem = gg_smem(NTs, cfg.ng, R, x3 ? 2 : 1, ldg);
   const double fl = (double)ntiles * (2.0 * (2.0 * S * S * 13 + 2.0 * S * 13 * 13) + 2.0 * (double)N * ldg);
   const double by = (double)ntiles * (S * 13 * (io ? 2.0 : 4.0) + stash_planes * 2.0 * ldg + (x3 ? 4.0 : 2.0) * N);
-#define GG_GO(NT, X3V, IOV, RV, NAME)                                                                                  \
+#define GG_GO(NT, X3V, IOV, NGV, NMV, RV, NAME)                                                                        \
   do {                                                                                                                 \
     static std::atomic<unsigned long long> done_{0};                                                                   \
-    if (ensure_dyn_smem((const void*)gcngi_fwd_kernel<NT, X3V, IOV, GG_NG, GG_NM, RV>, smem, done_) != WGNN_OK)        \
+    if (ensure_dyn_smem((const void*)gcngi_fwd_kernel<NT, X3V, IOV, NGV, NMV, RV>, smem, done_) != WGNN_OK)            \
       return WGNN_ERR_HIP;                                                                                             \
     PROF_LAUNCH(NAME, fl, by, st,                                                                                      \
-                hipLaunchKernelGGL((gcngi_fwd_kernel<NT, X3V, IOV, GG_NG, GG_NM, RV>), dim3(grid),                     \
-                                   dim3(64 * (GG_NG + GG_NM)), smem, st, ntiles, S, A, X, xt, io, W1, b1, W2, b2, ghi, \
+                hipLaunchKernelGGL((gcngi_fwd_kernel<NT, X3V, IOV, NGV, NMV, RV>), dim3(grid),                         \
+                                   dim3(64 * (NGV + NMV)), smem, st, ntiles, S, A, X, xt, io, W1, b1, W2, b2, ghi,     \
                                    glo, ldg, stash_planes, (const _Float16*)Bplanes, bplane, Np, GI, ldgi, N, status)); \
   } while (0)
 #define GG_CASE(NT)                                                                      \
-  if (x3 && !io) GG_GO(NT, true, false, 32, "gcngi_fwd_kernel<" #NT ">");                \
-  else if (x3) GG_GO(NT, true, true, 32, "gcngi_fwd_kernel<" #NT ">");                   \
-  else if (!io) GG_GO(NT, false, false, 64, "gcngi_fwd_kernel<" #NT ",f16>");            \
-  else GG_GO(NT, false, true, 64, "gcngi_fwd_kernel<" #NT ",f16>")
+  if (x3 && !io) GG_GO(NT, true, false, 8, 8, 32, "gcngi_fwd_kernel<" #NT ">");          \
+  else if (x3) GG_GO(NT, true, true, 8, 8, 32, "gcngi_fwd_kernel<" #NT ">");             \
+  else if (!io) GG_GO(NT, false, false, 12, 4, 48, "gcngi_fwd_kernel<" #NT ",f16>");     \
+  else GG_GO(NT, false, true, 12, 4, 48, "gcngi_fwd_kernel<" #NT ",f16>")
   switch (NTs) {
     case 1: GG_CASE(1); break;
     case 2: GG_CASE(2); break;

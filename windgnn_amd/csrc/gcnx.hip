@@ -34,8 +34,7 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
                                                        const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
                                                        const float* __restrict__ b2, _Float16* __restrict__ ghi,
-                                                       _Float16* __restrict__ glo, int ldp, unsigned* status,
-                                                       int exp_store) {
+                                                       _Float16* __restrict__ glo, int ldp, unsigned* status) {
   constexpr int KS = (NT + 1) / 2;
   constexpr int SP = 16 * NT;
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
@@ -224,8 +223,8 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
         if (64 * k < ldp / 2) {                                    // wave-uniform
           const int p = lane + 64 * k;
           if (p < ldp / 2) {
-            if (exp_store < 2) dh[p] = hi[k];
-            if (X3 && exp_store < 1) dl[p] = lo[k];
+            dh[p] = hi[k];
+            if (X3) dl[p] = lo[k];
           }
         }
       }
@@ -569,17 +568,11 @@ int launch_gcnx2_fwd(int ntiles, int S, const float* A, const void* X, int io, c
   const double by = (double)ntiles * S * 13 * (io ? 2.0 : 4.0) + (double)ntiles * S * 13 * 4.0;   // X in, g planes out
   int gx = cdiv_i(ntiles, FWD_WAVES);
   gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
-  // EXPERIMENT knobs (r4 latency probe; removed afterwards)
-  const char* e1 = getenv("WGNN_EXP_FWD_GRID");
-  const char* e2 = getenv("WGNN_EXP_FWD_LDS");
-  const char* e3 = getenv("WGNN_EXP_FWD_STORE");
-  if (e1) gx = atoi(e1);
-  const int exp_lds = e2 ? atoi(e2) : 0, exp_store = e3 ? atoi(e3) : 0;
   const dim3 grid(gx);
 #define FWD_LAUNCH(NT, X3V, IOV, NAME, BYTES)                                                                     \
   PROF_LAUNCH(NAME, fl, BYTES, st,                                                                                \
-              hipLaunchKernelGGL((gcnx_fwd_kernel<NT, X3V, IOV>), grid, dim3(64 * FWD_WAVES), exp_lds, st, ntiles, S, A, X, xt, io, W1, \
-                                 b1, W2, b2, ghi, glo, ldg, status, exp_store))
+              hipLaunchKernelGGL((gcnx_fwd_kernel<NT, X3V, IOV>), grid, dim3(64 * FWD_WAVES), 0, st, ntiles, S, A, X, xt, io, W1, \
+                                 b1, W2, b2, ghi, glo, ldg, status))
 #define FWD_CASE(NT)                                                                                              \
   if (x3 && !io) FWD_LAUNCH(NT, true, false, "gcnx_fwd_kernel<" #NT ">", by);                                     \
   else if (x3) FWD_LAUNCH(NT, true, true, "gcnx_fwd_kernel<" #NT ">", by);                                        \
