@@ -199,9 +199,8 @@ def test_two_rank_training_at_the_bench_shape_equals_single_process_and_the_orac
               % (math, tag, worst_ref, worst_orc, dp.max(), float((dp > 2e-5).mean())))
         assert worst_ref <= 2e-5, (tag, worst_ref)              # shard sums vs the big batch: rounding only
         assert worst_orc <= 1e-4, (tag, worst_orc)
-        # two Adam steps of ~1e-3 each: an element whose gradient sits at its tensor's rounding-noise level can move the
-        # other way (lr g / (|g| + 1e-8)); everything else agrees to 2e-5
-        assert dp.max() <= 2.1e-3 and float((dp > 2e-5).mean()) <= 2e-3, (tag, dp.max(), float((dp > 2e-5).mean()))
+        # two Adam steps of ~1e-3 each; observed (r4): every parameter within 1.3e-7 of the single-process run's
+        assert dp.max() <= 5e-6, (tag, dp.max())
 
 
 def test_rccl_allreduce_path_executes_and_is_bitwise_neutral_with_one_rank(tmp_path):

@@ -340,8 +340,8 @@ def test_full_size_B4096_mse_gradients_against_fp64_oracle(math):
     """ONE full-size MSE training step (the bench workload itself: S=34, T=24, B=4096, H=102, fp32 I/O) through TrainStep.step
     -- bench.py's own schedule: wgnn_fwd_loss, the three deferred backward parts, the fused wgnn_finish(6, adam) -- with ALL
     of Y, the loss and the 8 gradients compared against the fp64 oracle's step (src/main.py:66-79) at SURVEY 8(c)'s
-    tolerances, in every fp32-grade mode.  Observed (r4): Y 1.6e-6 / 2.0e-6 / 2.0e-6, worst gradient / tensor max
-    f32 1.4e-6, f16x3 1.3e-6, f16x3g 4e-6."""
+    tolerances, in every fp32-grade mode.  Observed (r4, gpurun_out/a5): Y 1.4e-6 / 2.2e-6 / 2.2e-6, worst gradient / tensor
+    max f32 3.1e-7, f16x3 9.6e-7, f16x3g 2.0e-6."""
     from windgnn_amd import GCN_GRU
     from windgnn_amd.trainer import TrainStep
     dev = _dev()
@@ -1421,3 +1421,82 @@ def test_fused_forward_front_end_is_bitwise_the_unfused_launches(S, T, B, H, mat
     assert torch.equal(a[5], b[5])
     for k in PARAM_KEYS:
         assert torch.equal(a[2][k], b[2][k]), k
+
+
+def test_wide_gru_mixed_mode_against_oracle_and_its_threshold():
+    """WGNN_MATH_F16X3G on the wide-GRU path (H > 127: the per-step GEMM recurrence BASELINE configs[4] runs): from
+    B*T = 3072 rows the dW_ih GEMM runs one MFMA pass and the dW_hh / dg GEMMs two (the lo plane of dGI / dGH stays unread);
+    below that it is f16x3 bit for bit.  MSE-driven gradients against the fp64 oracle at SURVEY 8(c)'s bar (observed 6e-6)."""
+    from oracle import windgnn_oracle as orc
+    dev = _dev()
+    S, T, H = 20, 24, 200
+    p = orc.init_params(S, 13, H, seed=5)
+    g = torch.Generator().manual_seed(77)
+    A = torch.rand(S, S, generator=g) / S + 0.01
+    for B, same in ((127, True), (130, False)):          # 3048 and 3120 rows
+        X = torch.rand(B, T, S, 13, generator=g)
+        L = torch.rand(B, T, H, generator=g)
+        res = {m: _run_step(_model_from(p, S, H, m), A.to(dev), X.to(dev), L.to(dev)) for m in ("f16x3", "f16x3g")}
+        assert torch.equal(res["f16x3"][0], res["f16x3g"][0])                      # the forward is the same code
+        if same:
+            for k in PARAM_KEYS:
+                assert torch.equal(res["f16x3"][2][k], res["f16x3g"][2][k]), k
+            continue
+        assert any(not torch.equal(res["f16x3"][2][k], res["f16x3g"][2][k]) for k in PARAM_KEYS)
+        Yo, loss_o, go = orc.train_step(A.double(), X.double(), L.double(), {k: v.double() for k, v in p.items()})
+        assert max_abs(res["f16x3g"][0].reshape(Yo.shape), Yo) <= Y_TOL
+        worst = {k: rel_to_max(res["f16x3g"][2][k], go[k]) for k in PARAM_KEYS}
+        print("wide-GRU f16x3g: %s" % {k: "%.1e" % v for k, v in worst.items()})
+        assert max(worst.values()) <= G_TOL, worst
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16x3g"])
+def test_4096_station_config_full_size_properties_B128_T24(math):
+    """BASELINE configs[4] at its OWN size on one GPU (S = 4096 CSR, H = 12288, B = 128 windows, T = 24: 3072 rows against
+    2.42 G parameters; the fp64 oracle cannot run here -- parity at this width is test_4096_station_config_at_full_width_*):
+    (a) windows are independent: the batch's Y equals its two halves' run separately, bit for bit;
+    (b) the backward is linear in dY and its range scale a power of two: grads(4 dY) == 4 grads(dY) exactly;
+    (c) gradients add over windows: grads(batch) ~= grads(half 1) + grads(half 2) -- 1e-5 of max in strict f16x3; in f16x3g
+        the full batch runs the one / two-pass GEMMs (3072 rows) and the halves the strict ones (1536), and dY here is pure
+        zero-mean noise (every gradient a fully cancelling sum: the worst case, as in test_full_size_properties_B4096): 1e-3."""
+    from windgnn_amd import GCN_GRU
+    from windgnn_amd.functional import gcn_gru_backward_raw, gcn_gru_forward_raw
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    dev = _dev()
+    S, T, B, H = 4096, 24, 128, 12288
+    csr = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=7), 8)).to(dev)
+    torch.manual_seed(11)
+    with torch.device(dev):
+        model = GCN_GRU(13, 13, 13, S * 13, H, math=math)
+    params = [q.detach() for q in model.hot_path_parameters()]
+    g = torch.Generator().manual_seed(128)
+    X = torch.rand(B, T, S, 13, generator=g).to(dev)
+    dY = ((torch.rand(B, T, H, generator=g) - 0.5) * 1e-6).to(dev)
+
+    def run(Xs, dYs):
+        Y, stash, d = gcn_gru_forward_raw(csr, Xs, params, model.math, want_stash=True)
+        grads = [torch.empty_like(q) for q in params]
+        gcn_gru_backward_raw(d, csr, Xs, params, Y, dYs, stash, grads)
+        return Y, grads
+
+    Y, G = run(X, dY)
+    Y1, G1 = run(X[: B // 2].contiguous(), dY[: B // 2].contiguous())
+    assert torch.equal(Y[: B // 2], Y1)                                                       # (a)
+    Y2, G2 = run(X[B // 2:].contiguous(), dY[B // 2:].contiguous())
+    assert torch.equal(Y[B // 2:], Y2)
+    tol = 1e-5 if math == "f16x3" else 1e-3
+    worst = 0.0
+    for k, a, b, c in zip(PARAM_KEYS, G, G1, G2):
+        b.add_(c)
+        e = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-30)
+        worst = max(worst, e)
+        assert e <= tol, (k, e)                                                               # (c)
+    print("c5 full size %s: additivity over halves %.1e of max" % (math, worst))
+    del G1, G2, Y1, Y2
+    _, G4 = run(X, (dY * 4.0).contiguous())
+    for k, a, b in zip(PARAM_KEYS, G, G4):
+        assert torch.equal(a * 4.0, b), k                                                     # (b)
+    from windgnn_amd.functional import check_range_status
+    check_range_status(dev)
+    del G, G4, params, model
+    torch.cuda.empty_cache()

@@ -22,6 +22,8 @@ def short(n):
         t = re.match(r"I((?:L[ib]\d+E)+)E", tail)      # <int..., bool X3>: bench.py prints X3 = false as ",f16"
         if t:
             args = re.findall(r"Li(\d+)E", t.group(1))
+            if name.startswith("gcngi"):                        # <NT, X3, IO, NG, NM, R>: the launcher prints NT (and ",f16") only
+                args = args[:1]
             flags = re.findall(r"Lb(\d)E", t.group(1))        # first bool = X3 (false: bench.py prints ",f16"); later
             if flags and flags[0] == "0":                       # flags (e.g. the TN GEMM's two-source A) are not printed
                 args.append("f16")

@@ -32,6 +32,7 @@ struct Layout {
   bool dg16;                                     // ... and dg itself ONE fp16 plane (dense GCN only)
   bool gi16;                                     // one-pass fp16 mode: the input projection GI is ONE fp16 plane
   bool dgi1;                                     // f16x3 at large B*T: dGI / dGHn are ONE fp16 plane, their three GEMMs run two passes
+  bool gen2p;                                    // f16x3g on the wide-GRU path: the three GEMMs skip the lo plane of dGI / dGH
   bool small, rec32;                             // exact fp32: one-window-per-workgroup recurrences / the register-resident MFMA ones
   size_t st_hprev;                               // exact fp32, large B*T: [Hprev | 1 | 0..] rows written by the forward recurrence
   bool dghn;                                     // only the n third of dGH is stored (dGHn): fast f16x3 recurrence; rec32 at large B*T
@@ -121,6 +122,10 @@ Layout make_layout(const wgnn_dims* d) {
   // element); it averages out in everything they feed -- the weight gradients sum B*T rows, the conv gradients B*T*S -- and
   // the lo plane is not written, staged or multiplied (error model and measured errors)
   L.dgi1 = d->math == WGNN_MATH_F16X3G && !L.gen_gru && L.BT >= 4096;
+  // ... and on the wide-GRU path (BASELINE configs[4]: H = 12288, B*T = 3072 per GPU; its BPTT cell kernel still writes both
+  // planes) the same three GEMMs simply leave dGI's / dGH's lo plane unread from B*T = 3072 rows: dW_ih one pass, dW_hh and dg
+  // two -- 128 of that configuration's 175 ms per step are these products
+  L.gen2p = d->math == WGNN_MATH_F16X3G && L.gen_gru && L.BT >= 3072;
   // (the GCN backward rounds dg to fp16 planes anyway: measured conv gradients 5.0e-6 vs 1.7e-6 in f16x3g; the one-pass
   // fp16 mode, whose own tolerance is 5e-2, takes it at every size)
   L.dg16 = (L.dgi1 || (d->math == WGNN_MATH_F16 && !L.gen_gru)) && !L.gen_gcn;
@@ -613,8 +618,8 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
         rc = launch_pgemm_tn(dGIh, dGIlo, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
                              L.sk_hh, part_hh, L.m_hh, (int)L.H + 1, full, dGHh, dGHnlo, L.hn, L.msplit, st, /*b_stream=*/true);
       } else {
-        rc = launch_pgemm_tn(dGHh, dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T, (int)L.BT,
-                             L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, full, nullptr, nullptr, 0, 0, st);
+        rc = launch_pgemm_tn(dGHh, L.gen2p ? nullptr : dGHh + PG, (int)L.Gp, yph, yph + (L.BT + 1) * L.Hp, (int)L.Hp, d->T,
+                             (int)L.BT, L.sk_hh, part_hh, (int)L.G3, (int)L.H + 1, full, nullptr, nullptr, 0, 0, st);
       }
       if (rc != WGNN_OK) return rc;
       // dW_ih | db_ih = dGI^T [g | 1]
@@ -622,8 +627,9 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       // out over the B*T rows this product sums: measured 8.8e-6 of max at B*T = 6144 against 5.9e-6 with g's lo plane.
       // The same was measured for dW_hh (7e-5: h rows are correlated) and dg (2.8e-4 on the conv gradients: the rounding
       // of W_ih is the same for every row and does not average) and NOT adopted: they keep hi x (hi + lo).)
-      rc = launch_pgemm_tn(dGIh, L.dgi1 ? dGIh : dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT,
-                           L.sk_ih, part_ih, (int)L.G3, (int)L.I + 1, full && !L.dgi1, nullptr, nullptr, 0, 0, st,
+      const bool one_pass_ih = L.dgi1 || L.gen2p;
+      rc = launch_pgemm_tn(dGIh, one_pass_ih ? dGIh : dGIh + PG, (int)L.Gp, gh, gh + L.BT * L.Ip, (int)L.Ip, 0, (int)L.BT,
+                           L.sk_ih, part_ih, (int)L.G3, (int)L.I + 1, full && !one_pass_ih, nullptr, nullptr, 0, 0, st,
                            /*b_stream=*/true);
       if (rc != WGNN_OK) return rc;
       if (!defer) rc = reduce_now(4);
@@ -635,7 +641,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, img_b, L.np_i, (int)L.Gp, status, st);
       if (rc != WGNN_OK) return rc;
     }
-    rc = launch_pgemm_nt(dGIh, L.gen_gru ? dGIh + PG : dGIlo, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.Id,
+    rc = launch_pgemm_nt(dGIh, L.gen_gru ? (L.gen2p ? nullptr : dGIh + PG) : dGIlo, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.Id,
                          (int)L.I, nullptr, full, nullptr, st, L.dg16);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gcn) {

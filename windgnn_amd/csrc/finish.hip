@@ -54,22 +54,34 @@ __device__ __forceinline__ void seg_tn(const FinishArgs& a, const FinSeg& s, int
                                        bool& bad_w) {
   const size_t slab4 = (size_t)s.ntiles * TN_WAVES * 5 * s.T * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;            // 64 quads x 4 z phases per block
-  const size_t q = (size_t)blk * 64 + tx;
-  const f32x4* src = (const f32x4*)s.partial + q;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  int z = ty;
-  for (; z + 12 < s.splitk; z += 16) {                               // 4 independent 16-byte loads in flight
-    s0 += src[(size_t)z * slab4];
-    s1 += src[(size_t)(z + 4) * slab4];
-    s2 += src[(size_t)(z + 8) * slab4];
-    s3 += src[(size_t)(z + 12) * slab4];
+  f32x4 v;
+  size_t q;
+  if (s.splitk < 4) {
+    // few K chunks (huge weight matrices: BASELINE configs[4] has ONE): a quad per thread, every lane busy -- with the 4
+    // z phases below three quarters of the block would idle through the loads (2.4 G elements: 36 ms of a 155 ms step)
+    q = (size_t)blk * 256 + threadIdx.x;
+    if (q >= slab4) return;
+    const f32x4* src = (const f32x4*)s.partial + q;
+    v = src[0];
+    for (int z = 1; z < s.splitk; ++z) v += src[(size_t)z * slab4];
+  } else {
+    q = (size_t)blk * 64 + tx;
+    const f32x4* src = (const f32x4*)s.partial + q;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int z = ty;
+    for (; z + 12 < s.splitk; z += 16) {                               // 4 independent 16-byte loads in flight
+      s0 += src[(size_t)z * slab4];
+      s1 += src[(size_t)(z + 4) * slab4];
+      s2 += src[(size_t)(z + 8) * slab4];
+      s3 += src[(size_t)(z + 12) * slab4];
+    }
+    for (; z < s.splitk; z += 4) s0 += src[(size_t)z * slab4];
+    __shared__ f32x4 red[4][64];
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty != 0) return;
+    v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
   }
-  for (; z < s.splitk; z += 4) s0 += src[(size_t)z * slab4];
-  __shared__ f32x4 red[4][64];
-  red[ty][tx] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (ty != 0) return;
-  f32x4 v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
   if (s.scaled) v *= a.scales[1];
   size_t t = q;
   const int lane = (int)(t % 64); t /= 64;
@@ -206,7 +218,10 @@ __global__ void __launch_bounds__(256) finish_kernel(const FinishArgs a) {
 }  // namespace
 
 int finish_seg_blocks(const FinSeg& s) {
-  if (s.kind == 2) return (int)((size_t)s.ntiles * TN_WAVES * 5 * s.T);      // slab4 / 64
+  if (s.kind == 2) {                                                           // slab4 / 64, or slab4 / 256 (seg_tn, few K chunks)
+    const size_t b64 = (size_t)s.ntiles * TN_WAVES * 5 * s.T;
+    return (int)(s.splitk < 4 ? (b64 + 3) / 4 : b64);
+  }
   if (s.kind == 1) return (int)(((size_t)s.Mgemm * s.pitch + 255) / 256);
   return 0;
 }
