@@ -247,11 +247,20 @@ __global__ void __launch_bounds__(64 * FWD_WAVES) gcnx_fwd_kernel(int ntiles, in
 // three waves per SIMD (166 VGPRs) hide more of it than two (measured 181 vs 198 us; 4-wave blocks, 2 per CU).
 // One-pass fp16 (no lo halves) fits 128 VGPRs: 16 waves, four per SIMD (122 vs 129 us).  f16x3 at 128 VGPRs spills 17
 // registers (268 vs 136 us) and stays at 12 waves.
-constexpr int bwd_waves(int NT, bool X3) { return (!X3 && NT <= 3) ? 16 : 12; }
+// S = 49..64 (NT = 4) in the split modes needs 172 VGPRs: 12 waves spilled 3-4 registers (16-20 B of scratch) and ran 132.8 us at
+// S = 64, B = 2048 against 118.3 us with 8 waves and no scratch (r4, tools/exp/gcnx_bwd_s64.py, same box)
+#ifndef WGNN_BWD4_WAVES
+#define WGNN_BWD4_WAVES 8
+#endif
+// DG16 = false in the one-pass mode (fp32 dg: only with a wide GRU behind a dense GCN) needs 131 VGPRs: 12 waves there too
+// (3 spilled registers at 16 waves; 51.0 -> 49.1 us at S = 34, H = 200, B = 2048)
+constexpr int bwd_waves(int NT, bool X3, bool DG16 = true) {
+  return (!X3 && NT <= 3 && DG16) ? 16 : (NT >= 4 && X3 ? WGNN_BWD4_WAVES : 12);
+}
 
 // DG16: dg arrives as ONE fp16 plane (pgemm_nt_kernel<.., OUT16>, WGNN_MATH_F16X3G) instead of fp32
 template <int NT, bool X3, bool IO, bool DG16>
-__global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
+__global__ void __launch_bounds__(64 * bwd_waves(NT, X3, DG16)) gcnx_bwd_kernel(int ntiles, int S, const float* __restrict__ A,
                                                        const void* __restrict__ X, const void* __restrict__ xtail, int io,
                                                        const float* __restrict__ W1,
                                                        const float* __restrict__ b1, const float* __restrict__ W2,
@@ -272,7 +281,7 @@ __global__ void __launch_bounds__(64 * bwd_waves(NT, X3)) gcnx_bwd_kernel(int nt
   // (split instances only: the one-pass ones, whose half steps run on the K = 32 form, measured 89.7 -> 92.5 us with it)
   constexpr bool HALF = X3 && (NT & 1) != 0;
   __shared__ __attribute__((aligned(8))) h4v sHA[HALF ? 2 * NT * 64 : 1], sHT[HALF ? 2 * NT * 64 : 1];
-  constexpr int BWD_WAVES = bwd_waves(NT, X3);
+  constexpr int BWD_WAVES = bwd_waves(NT, X3, DG16);
   __shared__ __attribute__((aligned(16))) float sbuf[BWD_WAVES * 2 * SP * XS];
   static_assert(2 * SP * XS >= PART, "the per-wave staging buffer doubles as its reduction row");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -605,7 +614,7 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
   const dim3 grid(grid_x(ntiles, S, x3));
 #define BWD_LAUNCH(NT, X3V, IOV, D16, NAME)                                                                       \
   PROF_LAUNCH(NAME, fl, by, st,                                                                                   \
-              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV, D16>), grid, dim3(64 * bwd_waves(NT, X3V)), 0, st, ntiles, S, A, X, xt, io, \
+              hipLaunchKernelGGL((gcnx_bwd_kernel<NT, X3V, IOV, D16>), grid, dim3(64 * bwd_waves(NT, X3V, D16)), 0, st, ntiles, S, A, X, xt, io, \
                                  W1, b1, W2, g, ldg, dg, ld_dg, scales, scale_in, partial))
 #define BWD_CASE(NT)                                                                                              \
   if (x3 && dg16 && !io) BWD_LAUNCH(NT, true, false, true, "gcnx_bwd_kernel<" #NT ">");                           \
