@@ -489,7 +489,10 @@ def main():
                                    "backward + grad all-reduce (N>1) + Adam; %s I/O"
                                    % (S, "" if args.workload == "c3" else " (symmetric 8-NN graph, CSR)", H, B, args.io),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "math": args.math,
-                       "collective": ("one rccl all-reduce per step: [loss | conv | GRU gradients], 0.67 MB, between wgnn_finish(6) and wgnn_finish(0, adam)"
+                       "collective": (("one rccl all-reduce per step: [loss | conv | GRU gradients], 0.67 MB, between wgnn_finish(6) and "
+                                       "wgnn_finish(0, adam)" + (", enqueued on the compute stream through the step's own communicator"
+                                                                 if trainer.exchange.direct is not None else
+                                                                 ", through torch.distributed (its own stream)"))
                                       if use_dist else "none (one rank)")},
             "loss": round(float(loss), 6),
             "roofline": roofline,
@@ -511,6 +514,7 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
+        trainer.close()
         dist.destroy_process_group()
 
 

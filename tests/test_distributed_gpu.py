@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32), stated=False, overlap=False):
+def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32), stated=False, overlap=False, direct=None):
     """`batches`: the global batch of each step (sharded over the ranks); `stated`: pass n_global to TrainStep.step
     instead of letting the exchange all-reduce the count; `overlap`: the two-collective form (the GRU gradients' all-reduce
     overlapped with backward part 2) instead of the default single all-reduce."""
@@ -45,8 +45,12 @@ def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32
     m = GCN_GRU(13, 13, 13, 7 * 13, 21, math="f16x3")
     m.load_state_dict({k: v.clone() for k, v in fx["params"].items()})
     m = m.to(dev)
-    tr = TrainStep(m, process_group=group, overlap_collectives=overlap)
+    tr = TrainStep(m, process_group=group, overlap_collectives=overlap, direct_rccl=direct)
     assert tr.collective == (world > 1 or backend == "nccl")
+    if backend == "nccl" and not overlap and direct is not False:
+        assert tr.exchange.direct is not None           # our own RCCL communicator, all-reduce on the compute stream
+    elif tr.collective:
+        assert tr.exchange.direct is None
     A = torch.from_numpy(fx["A"]).to(dev)
     X, L = torch.from_numpy(fx["X"]), torch.from_numpy(fx["L"])
     losses = []
@@ -60,6 +64,7 @@ def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32
         np.save(os.path.join(out_dir, "loss_%s.npy" % (tag or "world%d" % world)), np.array(losses))
     if world > 1 or backend == "nccl":
         dist.barrier()
+        tr.close()
         dist.destroy_process_group()
 
 
@@ -212,9 +217,12 @@ def test_rccl_allreduce_path_executes_and_is_bitwise_neutral_with_one_rank(tmp_p
     assert torch.cuda.is_available()
     mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "gloo", "plain"), nprocs=1, join=True)
     mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1"), nprocs=1, join=True)
+    mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1_torch", (32, 32), False, False, False), nprocs=1, join=True)
     mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1_overlap", (32, 32), False, True), nprocs=1, join=True)
     p0 = np.load(os.path.join(str(tmp_path), "p_plain.npy"))
-    for tag in ("rccl1", "rccl1_overlap"):        # the single all-reduce (default) and the two-collective form
+    # the single all-reduce through our own communicator on the compute stream (default: distributed.DirectRccl), the same
+    # through torch.distributed (its own stream), and the two-collective form
+    for tag in ("rccl1", "rccl1_torch", "rccl1_overlap"):
         assert np.array_equal(p0, np.load(os.path.join(str(tmp_path), "p_%s.npy" % tag))), tag
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "loss_plain.npy")),
                               np.load(os.path.join(str(tmp_path), "loss_%s.npy" % tag))), tag

@@ -51,6 +51,77 @@ def flatten(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
     return torch.cat([t.reshape(-1) for t in tensors])
 
 
+class DirectRccl:
+    """One RCCL communicator of our own, driven through ctypes, so that the gradient all-reduce is enqueued ON THE CALLER'S
+    STREAM: ncclAllReduce(bucket, bucket, n, ncclFloat32, ncclSum, comm, current stream) sits between wgnn_finish(6) and
+    wgnn_finish(0, adam) like any other kernel of the step.  torch.distributed's NCCL backend runs every collective on a
+    stream of its own and brackets it with two event dependencies; on this platform each such hop idles the queue for
+    ~10-20 us (profiles/r3_collective_path_one_rank.txt), i.e. more than the 0.67 MB all-reduce itself.
+
+    Bootstrap (the canonical one): rank 0 draws ncclGetUniqueId, the 128 bytes travel through the EXISTING torch process
+    group (one broadcast at construction), every rank calls ncclCommInitRank.  The library is the librccl.so torch itself
+    loaded (no second copy in the process).  Whether the direct path is used is decided COLLECTIVELY (a MIN all-reduce of
+    "I could load the library and my backend is nccl"): either every rank takes it or none does."""
+
+    _FLOAT32, _SUM = 7, 0                      # ncclDataType_t ncclFloat32, ncclRedOp_t ncclSum
+
+    def __init__(self, device: torch.device, group=None):
+        import ctypes as C
+        self.comm = None
+        self._lib = None
+        ok = 0
+        lib = None
+        try:
+            if dist.get_backend(group) == "nccl":
+                lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+                for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy", "ncclGetErrorString"):
+                    getattr(lib, name)
+                ok = 1
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)          # every rank, whatever its own answer
+        if int(flag.item()) == 0:
+            return
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_byte * 128)]
+
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = UniqueId()
+        rc0 = lib.ncclGetUniqueId(C.byref(uid)) if rank == 0 else 0
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8).to(device)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(t.cpu().tolist())
+        C.memmove(C.byref(uid), raw, 128)
+        comm = C.c_void_p()
+        torch.cuda.set_device(device)
+        rc = lib.ncclCommInitRank(C.byref(comm), world, uid, rank) if rc0 == 0 else rc0
+        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(good, op=dist.ReduceOp.MIN, group=group)          # again collectively: all or none
+        if int(good.item()) == 0:
+            if rc == 0:
+                lib.ncclCommDestroy(comm)
+            return
+        self._lib, self.comm = lib, comm
+
+    def all_reduce_(self, t: torch.Tensor) -> None:
+        """In-place fp32 sum over the ranks, enqueued on the current stream of t's device."""
+        rc = self._lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), self._FLOAT32, self._SUM, self.comm,
+                                     torch.cuda.current_stream(t.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError("windgnn_amd: ncclAllReduce failed: %s" % self._lib.ncclGetErrorString(rc).decode())
+
+    def close(self) -> None:
+        if self.comm is not None:
+            self._lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
 class BucketExchange:
     """The collectives of one data-parallel step over a flat bucket `[4-float header | conv grads | GRU grads]`.
 
@@ -59,11 +130,20 @@ class BucketExchange:
     The global window count either comes from the caller (`n_global`, e.g. bench.py's fixed world * B: no extra
     collective, no host sync) or is all-reduced on EVERY call."""
 
-    def __init__(self, bucket: torch.Tensor, n_conv: int, group=None):
+    def __init__(self, bucket: torch.Tensor, n_conv: int, group=None, direct=None):
         self.bucket = bucket
         self.n_conv = n_conv
         self.group = group
         self.world = dist.get_world_size(group)
+        # the single all-reduce on the compute stream through our own RCCL communicator (GPU buckets on the nccl backend;
+        # WGNN_RCCL_DIRECT=0 or direct=False keeps torch.distributed's own stream); the decision is taken collectively
+        if direct is None:
+            direct = os.environ.get("WGNN_RCCL_DIRECT", "1") != "0"
+        self.direct = None
+        if direct and bucket.is_cuda:
+            d = DirectRccl(bucket.device, group)
+            if d.comm is not None:
+                self.direct = d
 
     def shard_weight(self, n_local: int, n_global: Optional[int] = None) -> float:
         """n_local / n_global: the dY scale of this shard and the weight of its mean loss in the global mean."""
@@ -82,7 +162,10 @@ class BucketExchange:
         waits for it; no host sync).  What TrainStep runs by default: see trainer.py for the measurement behind it."""
         if weight != 1.0:
             self.bucket[LOSS_SLOT].mul_(weight)
-        dist.all_reduce(self.bucket, group=self.group)       # the whole, 16-byte aligned bucket (header words 0-2 are zeros)
+        if self.direct is not None:
+            self.direct.all_reduce_(self.bucket)             # on the compute stream: no stream hop around 0.67 MB
+        else:
+            dist.all_reduce(self.bucket, group=self.group)   # the whole, 16-byte aligned bucket (header words 0-2 are zeros)
 
     def start_gru(self):
         """Sum the GRU gradients (final after backward parts 1|4); returns the async work handle."""

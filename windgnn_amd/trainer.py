@@ -30,7 +30,7 @@ from .modules import GCN_GRU
 
 class TrainStep:
     def __init__(self, model: GCN_GRU, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, check_every: int = 100, overlap_collectives: bool = False):
+                 process_group=None, check_every: int = 100, overlap_collectives: bool = False, direct_rccl=None):
         self.model = model
         self.params = list(model.hot_path_parameters())
         sizes = [p.numel() for p in self.params]
@@ -64,7 +64,12 @@ class TrainStep:
         # an explicitly passed group runs the collective path even with one rank (the all-reduces execute)
         self.collective = self.world > 1 or process_group is not None
         self.overlap_collectives = overlap_collectives
-        self.exchange = BucketExchange(self._gbuf, self.n_conv, process_group) if self.collective else None
+        # direct_rccl: None = on for GPU buckets on the nccl backend unless WGNN_RCCL_DIRECT=0 (distributed.DirectRccl); the
+        # two-collective form overlaps through torch.distributed's own stream by design and never takes it
+        self.exchange = None
+        if self.collective:
+            self.exchange = BucketExchange(self._gbuf, self.n_conv, process_group,
+                                           False if (overlap_collectives and direct_rccl is None) else direct_rccl)
         self.check_every = check_every          # f16x3 / f16: read the library's range-status word every N steps
         self.device = dev
 
@@ -195,6 +200,12 @@ class TrainStep:
         if self.check_every and self.model.math != _lib.MATH_F32 and self.steps % self.check_every == 0:
             self.check()
         return loss, Y
+
+    def close(self):
+        """Release the step's own RCCL communicator, if it has one (before torch.distributed.destroy_process_group)."""
+        if self.exchange is not None and self.exchange.direct is not None:
+            self.exchange.direct.close()
+            self.exchange.direct = None
 
     def check(self):
         """Raise if a kernel of the fp16-plane modes reported a value outside fp16's range (one 4-byte read)."""
