@@ -1106,7 +1106,9 @@ def test_raw_entry_points_refuse_strided_tensors_and_trainstep_copies_them():
 
 @pytest.mark.parametrize("math", ["f32", "f16x3", "f16x3g", "f16"])
 @pytest.mark.parametrize("S,T,B,H,csr", [(34, 24, 256, 102, False), (7, 12, 32, 21, False), (5, 3, 17, 9, False),
-                                         (20, 4, 6, 200, False), (100, 3, 4, 60, True), (64, 2, 3, 127, False)])
+                                         (20, 4, 6, 200, False), (100, 3, 4, 60, True), (64, 2, 3, 127, False),
+                                         # S*13 and 3H multiples of 4: the wide (8-byte, quad-transposed) image stores of finish
+                                         (4, 3, 5, 4, False), (8, 5, 9, 12, False), (28, 6, 40, 100, False)])
 def test_finish_kernel_equals_the_separate_reduce_adam_and_prepare_passes(S, T, B, H, csr, math):
     """wgnn_finish (one launch: deferred split-K / per-workgroup partial sums -> gradients, Adam, the staged W_ih images)
     against the passes it replaces (tn_reduce / splitk_reduce x2, gcn_partial_reduce, wgnn_adam_step, wgnn_prepare_weights)

@@ -9,15 +9,17 @@
 // reduce-only launches (GRU part early, conv part late) and one Adam + prepare launch that reads the summed bucket.
 // Every sum has a fixed order: results are bitwise reproducible and identical between the fused and the split form.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int FP = 16, PART = 2 * FP * FP + 2 * FP;   // GCN partial row: dW1 | dW2 | db1 | db2 (gcn.hip)
 enum { T_C1W = 0, T_C1B, T_C2W, T_C2B, T_WIH, T_WHH, T_BIH, T_BHH };
 
-template <int ADAM>   // 1: Adam + prepared images after the reduction; 0: reduce only
+// IMG = false: the caller writes the prepared images itself (seg_tn's wide stores); *wout receives the new weight
+template <int ADAM, bool IMG = true>   // ADAM 1: Adam + prepared images after the reduction; 0: reduce only
 __device__ __forceinline__ void emit(const FinishArgs& a, int t, int64_t idx, int row, int col, float gval, bool write_g,
-                                     bool& bad_g, bool& bad_w) {
+                                     bool& bad_g, bool& bad_w, float* wout = nullptr) {
   bad_g |= !(__builtin_fabsf(gval) <= 3.0e38f);                       // inf / NaN in a final gradient
   if (write_g) a.g[t][idx] = gval;
   if (!ADAM) return;
@@ -29,11 +31,14 @@ __device__ __forceinline__ void emit(const FinishArgs& a, int t, int64_t idx, in
   const float denom = __fadd_rn(__fmul_rn(__fsqrt_rn(vi), a.inv_sqrt_bc2), a.eps);
   const float w = __fsub_rn(a.p[t][idx], __fmul_rn(a.lr_over_bc1, __fdiv_rn(mi, denom)));
   a.p[t][idx] = w;
+  if (!IMG) { *wout = w; return; }
   if (a.prep_kind == 0 || (t != T_WIH && t != T_BIH)) return;
   if (t == T_BIH) { col = a.I; row = (int)idx; }                           // b_ih rides in column I of the forward image
   if (a.prep_kind == 1) {
     bad_w |= out_of_fp16_range(w);
-    const _Float16 h = (_Float16)w, l = (_Float16)(w - (float)h);
+    float ws = w;
+    asm volatile("" : "+v"(ws));          // split the stored fp32 value (no fp16-output fma contraction: see seg_tn)
+    const _Float16 h = (_Float16)ws, l = (_Float16)(ws - (float)h);
     const size_t f = (size_t)(col >> 5) * a.np_g3 * 32 + (size_t)row * 32 + (col & 31);
     a.pf_hi[f] = h;
     a.pf_lo[f] = l;
@@ -93,6 +98,58 @@ __device__ __forceinline__ void seg_tn(const FinishArgs& a, const FinSeg& s, int
   const int n = nb * 32 * s.T + 16 * (s.T * wn + j) + (lane & 15);
   const int m0 = mb * TN_BM + 80 * wm + 16 * i + 4 * (lane >> 4);
   if (n >= s.Nout) return;
+  // Wide image stores (W_ih with fp16-plane images, dimensions that are multiples of 4 -- BASELINE configs[4]: 36864 x 53248):
+  // the thread's 4 consecutive rows of one column are 4 consecutive halfs of the W_ih^T image (one 8-byte store per plane),
+  // and a 4 x 4 transpose inside the lane quad (two DPP exchanges) turns its 4 rows x the quad's 4 columns into one row x 4
+  // consecutive columns of the forward image (one 8-byte store per plane) -- instead of sixteen 2-byte stores per thread, which
+  // ran the 15.8 GB of image writes of that configuration at 1.3 TB/s (12.4 of the finish launch's 32.8 ms)
+  if (ADAM && tw == T_WIH && a.prep_kind == 1 && s.msplit == 0 && (s.ncols & 3) == 0 && (s.Mout & 3) == 0 && n < s.ncols &&
+      m0 < s.Mout) {
+    unsigned pk[4];                                                    // hi | lo << 16 of the new weights, rows m0 .. m0 + 3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float w;
+      emit<ADAM, false>(a, tw, (int64_t)(m0 + r) * s.ncols + n, m0 + r, n, v[r], true, bad_g, bad_w, &w);
+      // the image is the split of the STORED fp32 weight: without the barrier hipcc contracts "fp16(p - lr q)" into ONE
+      // v_fma_mixlo_f16 (a single rounding of the exact value), which differs from fp16(fp32(..)) at exact ties -- the
+      // image would no longer be bit-identical to wgnn_prepare_weights of the parameters (4 of 156 000 elements in the test)
+      asm volatile("" : "+v"(w));
+      bad_w |= out_of_fp16_range(w);
+      const _Float16 h = (_Float16)w, l = (_Float16)(w - (float)h);
+      pk[r] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+    }
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    {  // W_ih^T image: (row, col) at [(row >> 5)][col][row & 31]
+      const size_t b = (size_t)(m0 >> 5) * a.np_i * 32 + (size_t)n * 32 + (m0 & 31);
+      us4 hh, ll;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { hh[r] = (unsigned short)(pk[r] & 0xffffu); ll[r] = (unsigned short)(pk[r] >> 16); }
+      *(us4*)(a.pb_hi + b) = hh;
+      *(us4*)(a.pb_lo + b) = ll;
+    }
+    {  // forward image: (row, col) at [(col >> 5)][row][col & 31]; quad transpose: lane L of the quad ends with row m0 + L
+      const int L = lane & 3;
+      const bool odd = L & 1, upper = L & 2;
+      auto xch = [](unsigned x, auto ctrl) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, 0xF, 0xF, false);
+      };
+      using X1 = std::integral_constant<int, 0xB1>;                    // quad_perm [1,0,3,2]: lane ^ 1
+      using X2 = std::integral_constant<int, 0x4E>;                    // quad_perm [2,3,0,1]: lane ^ 2
+      // step 1 (lane ^ 1): even lanes end with rows {0, 2} x columns {c, c + 1}, odd lanes with rows {1, 3} x {c - 1, c}
+      const unsigned r0 = xch(odd ? pk[0] : pk[1], X1{}), r1 = xch(odd ? pk[2] : pk[3], X1{});
+      const unsigned b0 = odd ? r0 : pk[0], b1 = odd ? pk[1] : r0, b2 = odd ? r1 : pk[2], b3 = odd ? pk[3] : r1;
+      // step 2 (lane ^ 2): lanes 0, 1 keep their first row (columns 0, 1) and receive its columns 2, 3; lanes 2, 3 the second
+      const unsigned s0 = xch(upper ? b0 : b2, X2{}), s1 = xch(upper ? b1 : b3, X2{});
+      const unsigned c0 = upper ? s0 : b0, c1 = upper ? s1 : b1, c2 = upper ? b2 : s0, c3 = upper ? b3 : s1;
+      const int row = m0 + L, col = n - L;                             // this lane's row, the quad's first column
+      const size_t f = (size_t)(col >> 5) * a.np_g3 * 32 + (size_t)row * 32 + (col & 31);
+      us4 hh = {(unsigned short)(c0 & 0xffffu), (unsigned short)(c1 & 0xffffu), (unsigned short)(c2 & 0xffffu), (unsigned short)(c3 & 0xffffu)};
+      us4 ll = {(unsigned short)(c0 >> 16), (unsigned short)(c1 >> 16), (unsigned short)(c2 >> 16), (unsigned short)(c3 >> 16)};
+      *(us4*)(a.pf_hi + f) = hh;
+      *(us4*)(a.pf_lo + f) = ll;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     int m = m0 + r;

@@ -559,7 +559,10 @@ __global__ void nt_ksum_kernel(const float* __restrict__ part, int nchunks, size
 // NT tiling of N: nsl slices of 32T columns (T <= 14: two stages of (192 + 448) 128-byte rows are exactly the
 // CU's 160 KB of LDS), as few slices as possible and as narrow as they can be -- unless that leaves most CUs
 // without a workgroup (few rows: the per-step GEMMs of a wide GRU, small batches), in which case N is cut finer.
-constexpr int NT_KC = 2048;   // K chunk of long contractions: <= 64 chained MFMA steps per fp32 accumulator
+#ifndef WGNN_NT_KC
+#define WGNN_NT_KC 2048
+#endif
+constexpr int NT_KC = WGNN_NT_KC;   // K chunk of long contractions: <= 64 chained MFMA steps per fp32 accumulator
 static int nt_chunks(int Kp) { return Kp > NT_KC + NT_KC / 2 ? cdiv_i(Kp, NT_KC) : 1; }
 static void nt_shape(int M, int N, int Kp, bool splitk, int& nsl, int& T) {
   nsl = cdiv_i(N, 448);
