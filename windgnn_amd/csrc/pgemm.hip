@@ -559,10 +559,15 @@ __global__ void nt_ksum_kernel(const float* __restrict__ part, int nchunks, size
 // NT tiling of N: nsl slices of 32T columns (T <= 14: two stages of (192 + 448) 128-byte rows are exactly the
 // CU's 160 KB of LDS), as few slices as possible and as narrow as they can be -- unless that leaves most CUs
 // without a workgroup (few rows: the per-step GEMMs of a wide GRU, small batches), in which case N is cut finer.
+// K chunk of long contractions: <= 128 chained MFMA steps per fp32 accumulator, then the chunk's sum is added onto C (two-level
+// summation).  4096 since round 4 (2048 before): every chunk of the 4096-station projections re-reads and re-writes the whole
+// C (453 / 654 MB per chunk for GI / dg at B*T = 3072), so half the chunks = 11.7 GB less traffic and half the launches:
+// configs[4] 142.3 -> 132.4 ms per step, with Y / gradients at full width still inside the same bounds
+// (test_4096_station_config_at_full_width_H12288_against_host_fp64; a single 53 248-long chain measured 4e-5 / 2.5e-4)
 #ifndef WGNN_NT_KC
-#define WGNN_NT_KC 2048
+#define WGNN_NT_KC 4096
 #endif
-constexpr int NT_KC = WGNN_NT_KC;   // K chunk of long contractions: <= 64 chained MFMA steps per fp32 accumulator
+constexpr int NT_KC = WGNN_NT_KC;
 static int nt_chunks(int Kp) { return Kp > NT_KC + NT_KC / 2 ? cdiv_i(Kp, NT_KC) : 1; }
 static void nt_shape(int M, int N, int Kp, bool splitk, int& nsl, int& T) {
   nsl = cdiv_i(N, 448);
@@ -596,8 +601,8 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
   if (ensure_dyn_smem((const void*)pgemm_nt_kernel<T, false, true, false>, smem1, done16) != WGNN_OK) return WGNN_ERR_HIP;
   static const std::string name = "pgemm_nt_kernel<" + std::to_string(T) + ">", name16 = "pgemm_nt_kernel<" + std::to_string(T) + ",f16>",
                            name2 = "pgemm_nt_kernel<" + std::to_string(T) + ",x2>";
-  // Long contractions (the 4096-station projections: K = 53 248) run as 2048-wide K chunks: an fp32 accumulator
-  // chain of at most 64 MFMA steps per chunk keeps the summation error at fp32-GEMM level.  With split-K scratch
+  // Long contractions (the 4096-station projections: K = 53 248) run as NT_KC-wide K chunks: an fp32 accumulator
+  // chain of at most NT_KC / 32 MFMA steps per chunk keeps the summation error at fp32-GEMM level.  With split-K scratch
   // the chunks are blocks of ONE launch (partials summed in fixed order); without, one launch per chunk adds onto C.
   // (a one-pass fp16 product with fp16 C is in the 5e-2 tolerance class anyway: one chunk of any length)
   const int nchunks = (out16 && !x3) ? 1 : nt_chunks(Kp), kc_len = nchunks > 1 ? NT_KC : Kp;
