@@ -79,7 +79,10 @@ typedef enum wgnn_math {
                           per element, that averages out over the B*T rows a weight gradient sums -- observed <= 9e-6 of
                           the tensor's max against the fp64 oracle at B*T = 6144 with the MSE loss (F16X3: 1.3e-6), and
                           at worst ~4e-4 when dY is pure zero-mean noise (a gradient that is itself a fully cancelling
-                          sum).  Below 4096 rows it IS F16X3, bit for bit. */
+                          sum); 2.0e-6 at B*T = 98304 (F16X3: 9.6e-7).  Below 4096 rows it IS F16X3, bit for bit.
+                          With a hidden state wider than the register-resident recurrence (H > 127: the per-step GEMM
+                          recurrence) the planes are still written in full and the three GEMMs leave the lo plane of dGI /
+                          dGH unread from B*T >= 3072 rows (dW_ih one pass, dW_hh and dg two); below that F16X3. */
 } wgnn_math;
 
 /* Adjacency argument `A` of wgnn_fwd / wgnn_bwd:
@@ -158,7 +161,11 @@ size_t wgnn_workspace_bytes(const wgnn_dims* d);
 size_t wgnn_stash_bytes(const wgnn_dims* d);
 
 /* Y[B,T,H] = GRU(relu(A relu(A X W1 + b1) W2 + b2)), h0 = 0 per window.
- * stash may be NULL (inference: src/main.py:100-102); otherwise it receives what wgnn_bwd needs. */
+ * stash may be NULL (inference: src/main.py:100-102); otherwise it receives what wgnn_bwd needs.
+ * In the fp16-plane math modes with a dense adjacency and H <= 127 a stash-less call (and wgnn_fwd_last) runs both graph
+ * convolutions and the GRU input projection as ONE kernel whose intermediate g never leaves the chip (csrc/gcngi.hip); the
+ * environment variable WGNN_FUSED_FWD selects: unset / "1" stash-less forwards, "2" every supported forward, "0" never.
+ * The results do not depend on it (bit-identical either way). */
 int wgnn_fwd(const wgnn_dims* d, const float* A, const void* X /* d->io */, const wgnn_params* p, void* Y /* d->io */,
              void* stash, void* workspace, size_t workspace_bytes, void* stream);
 
