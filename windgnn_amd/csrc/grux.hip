@@ -159,7 +159,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
   // WRONG for trained weights -- saturated gates need r (1 - r) to fp32's own precision (8 % gradient error on the
   // wind_gnn_7.pth fixture).
   const int NW = (H + 15) / 16;
-  constexpr int GREC = IO ? 5 : 4;
+  // One-pass fp16 mode (X3 = false; tolerance class 5e-2): the record is fp16 -- [r | z] and [n | gh_n] as two 8-half
+  // (16-byte) components -- half the stash bytes of the two recurrences, which are bound by exactly those bytes at the bench
+  // size.  (Evaluated on the fp64 oracle in round 3: gradient errors 0.9-2.8e-4 of max, independent of B: outside the 1e-4
+  // bar of the split modes, far inside this mode's.)  The h_t component of 16-bit I/O stays fp32.
+  constexpr int GREC = X3 ? (IO ? 5 : 4) : (IO ? 3 : 2);       // 16-byte components per lane and (t, wave)
   f32x4* gatesw = gates ? (f32x4*)gates + ((size_t)blockIdx.x * T * NW + wave) * GREC * 64 + lane : nullptr;
   int rowt[4];            // (local window row) * T, clamped to the last valid window
   bool rowok[4];
@@ -296,13 +300,26 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       }
       if (gates) {
         f32x4* rec = gatesw + (size_t)t * NW * GREC * 64;
-        rec[0] = rg4;
-        rec[64] = zg4;
-        rec[128] = ng4;
-        rec[192] = an;
+        if (X3) {
+          rec[0] = rg4;
+          rec[64] = zg4;
+          rec[128] = ng4;
+          rec[192] = an;
+        } else {
+          h8 rz, ng;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            rz[r] = (_Float16)rg4[r];
+            rz[4 + r] = (_Float16)zg4[r];
+            ng[r] = (_Float16)ng4[r];
+            ng[4 + r] = (_Float16)an[r];
+          }
+          rec[0] = __builtin_bit_cast(f32x4, rz);
+          rec[64] = __builtin_bit_cast(f32x4, ng);
+        }
         if (IO) {
           const f32x4 h4 = {hnew[0], hnew[1], hnew[2], hnew[3]};
-          rec[256] = h4;
+          rec[(GREC - 1) * 64] = h4;
         }
       }
     }
@@ -479,11 +496,11 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     WT[ks] = split_vals(x);
   }
   const int NW = (H + 15) / 16;                              // gate stash: grux_fwd_kernel's register layout
-  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * (IO ? 5 : 4) * 64 + lane;
+  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * (X3 ? (IO ? 5 : 4) : (IO ? 3 : 2)) * 64 + lane;
   // 16-bit I/O: Y on the wire is rounded, so h_{t-1} (and the Y of the fused dY) is the 5th component of the stash
   // records; explicit dY is always fp32; labels are io-typed and come in through LDS as whole rows (see grux_fwd_kernel)
   constexpr int esz = IO ? 2 : 4;
-  constexpr int GREC = IO ? 5 : 4;
+  constexpr int GREC = X3 ? (IO ? 5 : 4) : (IO ? 3 : 2);       // as grux_fwd_kernel: fp16 records in the one-pass mode
   const void* Labw = Lab ? (const char*)Lab + (size_t)b0 * T * H * esz : nullptr;
   const float* dYw = dY ? dY + (size_t)b0 * T * H : nullptr;
   const float* Yw = (const float*)Y + (size_t)b0 * T * H;
@@ -578,7 +595,19 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   auto load_step = [&](int t, StepIn& s) {
     const int tc = t > 0 ? t : 0;
     const f32x4* rec = gatesw + (size_t)tc * NW * GREC * 64;
-    const f32x4 r4 = rec[0], z4 = rec[64], n4 = rec[128], g4 = rec[192];
+    f32x4 r4, z4, n4, g4;
+    if (X3) {
+      r4 = rec[0]; z4 = rec[64]; n4 = rec[128]; g4 = rec[192];
+    } else {
+      const h8 rz = __builtin_bit_cast(h8, rec[0]), ng = __builtin_bit_cast(h8, rec[64]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        r4[r] = (float)rz[r];
+        z4[r] = (float)rz[4 + r];
+        n4[r] = (float)ng[r];
+        g4[r] = (float)ng[4 + r];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int bt = rowt[r] + tc;
@@ -592,7 +621,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
       s.hp[r] = tc > 0 ? hp : 0.f;
     }
     if (IO && tc > 0) {                                  // h_{t-1} = 5th component of step t-1's record
-      const f32x4 h4 = (gatesw + (size_t)(tc - 1) * NW * GREC * 64)[256];
+      const f32x4 h4 = (gatesw + (size_t)(tc - 1) * NW * GREC * 64)[(GREC - 1) * 64];
 #pragma unroll
       for (int r = 0; r < 4; ++r) s.hp[r] = h4[r];
     }
@@ -602,7 +631,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
   float ycur[4] = {0.f, 0.f, 0.f, 0.f};
   if (Lab) {
     if (IO) {
-      const f32x4 h4 = (gatesw + (size_t)(T - 1) * NW * GREC * 64)[256];
+      const f32x4 h4 = (gatesw + (size_t)(T - 1) * NW * GREC * 64)[(GREC - 1) * 64];
 #pragma unroll
       for (int r = 0; r < 4; ++r) ycur[r] = h4[r];
     } else {
@@ -692,6 +721,11 @@ size_t grux_gates_floats(int B, int T, int H, int io) {
   return (size_t)cdiv_i(B, MB) * T * cdiv_i(H, 16) * grec(io) * 64 * 4;
 }
 int grux_blocks(int B) { return cdiv_i(B, MB); }
+// bytes the recurrences really move for the stash: fp16 records in the one-pass mode (grux_gates_floats() sizes the buffer
+// for the split modes' fp32 records whatever the mode)
+static double gates_bytes(int B, int T, int H, int io, bool x3) {
+  return (double)cdiv_i(B, MB) * T * cdiv_i(H, 16) * (x3 ? grec(io) : (io ? 3 : 2)) * 64 * 16.0;
+}
 
 int launch_grux_fwd(int B, int T, int H, const void* GI /*fp32 rows (x3) or fp16 rows (one-pass fp16)*/, int ldgi, const float* Whh, const float* bhh, void* Y,
                     float* gates, void* y_planes /*nullable: 2 x [B*T+1][grux_hp(H)] halfs*/, bool x3, unsigned* status,
@@ -704,7 +738,7 @@ int launch_grux_fwd(int B, int T, int H, const void* GI /*fp32 rows (x3) or fp16
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H,
                by = bt * ((x3 ? 4.0 : 2.0) * 3 * H + (io ? 2.0 : 4.0) * ((last_only ? 0 : H) + (labels ? H : 0))) +
-                    (gates ? 4.0 * grux_gates_floats(B, T, H, io) : 0.0);
+                    (gates ? gates_bytes(B, T, H, io, x3) : 0.0);
   const dim3 grid(cdiv_i(B, MB));
 #define FLAUNCH(K, X3V, IOV, NAME)                                                                                 \
   PROF_LAUNCH(NAME, fl, by, st,                                                                                    \
@@ -748,7 +782,7 @@ int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const 
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H,
                by = bt * ((io ? 2.0 + 4.0 : 4.0 + 4.0) * H + (x3 && write_lo ? 4.0 : 2.0) * (3 * H + H)) +
-                    4.0 * grux_gates_floats(B, T, H, io);      // Y + labels in, dGI + dGHn planes out (hi [+ lo]), gate stash in
+                    gates_bytes(B, T, H, io, x3);              // Y + labels in, dGI + dGHn planes out (hi [+ lo]), gate stash in
   const dim3 grid(cdiv_i(B, MB));
 #define BLAUNCH(K, X3V, IOV, NAME, BYTES)                                                                         \
   PROF_LAUNCH(NAME, fl, BYTES, st,                                                                                \
