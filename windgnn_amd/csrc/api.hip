@@ -39,6 +39,8 @@ struct Layout {
   int hn, msplit, m_hh;                          // its row width, its first GEMM row, GEMM rows of the dW_hh product
   size_t st_h1;                                  // general GCN: layer-1 activations
   size_t st_stats;                               // wgnn_fwd_loss: MSE partial pairs (sum | max) of the forward recurrence
+  size_t st_GI;                                  // split modes, register-resident recurrence: GI lives in the stash (BPTT recomputes n from its n third)
+  bool gi_stash;
   size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_kp_f, ws_hc, ws_du, ws_dhz, ws_dhw, ws_hhp_b, ws_kp_b, ws_dc;   // general GRU / GCN scratch
 };
 
@@ -114,6 +116,10 @@ Layout make_layout(const wgnn_dims* d) {
     const size_t nb = L.small ? (size_t)gru_small_blocks(d->B) : (size_t)grux_blocks(d->B);
     L.st_stats = o; o += al(2 * nb + 4);
   }
+  // split fp16 modes with the register-resident recurrence: the gate records hold r | z | gh_n only and the BPTT kernel forms
+  // n = tanh(gi_n + r gh_n) from GI, so GI (which the projection GEMM writes anyway) goes into the stash, not the workspace
+  L.gi_stash = x3 && !L.gen_gru && (d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G);
+  L.st_GI = o; o += al(L.gi_stash ? L.BT * L.Gp : 0);
   L.hq = (int)rup(L.H + 1, 16);
   L.st_hprev = o; o += al(L.g32tn ? L.BT * (size_t)L.hq : 0);     // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
   L.stash_floats = o;
@@ -312,7 +318,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
   if (last && !(L.x3 && !L.gen_gru) && !L.rec32) Y = ws + L.ws_Ylast;   // these recurrences write every row: then read the last one out
   unsigned* status = (unsigned*)workspace;           // word 0 of the status block (include/windgnn.h)
   float* sf = (float*)stash;
-  float* GI = ws + L.ws_GI;
+  float* GI = (sf && L.gi_stash) ? sf + L.st_GI : ws + L.ws_GI;
   float* g = sf ? sf + L.st_g : ws + L.ws_g;
   float* gates = sf ? sf + L.st_gates : nullptr;
   const bool x3 = L.x3;                              // fp16-plane kernels
@@ -604,7 +610,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
                                    (int)L.Gp, ws + L.ws_dhz, ws + L.ws_dhw, ws + L.ws_kp_b, ws + L.ws_dc, full, st);
       } else {
         rc = launch_grux_bwd(d->B, d->T, d->H, p->w_hh, Yv, fused_loss ? nullptr : dY, fused_loss ? labelsv : nullptr,
-                             d->io, gates, scales, dGIh, dGHh, (int)L.Gp, full,
+                             d->io, gates, L.gi_stash ? sf + L.st_GI : nullptr, (int)L.Gp, scales, dGIh, dGHh, (int)L.Gp, full,
                              fused_loss && stats_ready ? sf + L.st_stats : nullptr, (int64_t)L.BT * L.H, grad_scale, loss,
                              scales, status, L.dgi1 ? 0 : 1, st);
       }

@@ -128,7 +128,7 @@ int grux_msplit(int H);   // 8*ceil(2H/8): first GEMM row of the dGHn block in t
 // stat_part != null (the partial pairs + tag wgnn_fwd_loss left in the stash): loss[0], scales_out[0..2] are finalised inside
 // the kernel (n_loss = B*T*H, grad_scale as in wgnn_bwd_mse_part); a missing tag gives loss = NaN + WGNN_STATUS_NO_LOSS_STATS
 int launch_grux_bwd(int B, int T, int H, const float* Whh, const void* Y, const float* dY, const void* labels, int io,
-                    const float* gates,
+                    const float* gates, const float* GI /*split modes: the forward's GI rows (stash), n recomputed*/, int ldgi,
                     const float* scales, void* dGI_planes, void* dGHn_planes, int ldd, bool x3, const float* stat_part,
                     int64_t n_loss, float grad_scale, float* loss, float* scales_out, unsigned* status,
                     int write_lo /*0: dGI / dGHn as one fp16 plane (x3 only)*/, hipStream_t st);
