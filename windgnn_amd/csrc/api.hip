@@ -118,7 +118,7 @@ Layout make_layout(const wgnn_dims* d) {
   }
   // split fp16 modes with the register-resident recurrence: the gate records hold r | z | gh_n only and the BPTT kernel forms
   // n = tanh(gi_n + r gh_n) from GI, so GI (which the projection GEMM writes anyway) goes into the stash, not the workspace
-  L.gi_stash = x3 && !L.gen_gru && (d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G);
+  L.gi_stash = (x3 && !L.gen_gru && (d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G)) || L.rec32;   // (and gru.hip's)
   L.st_GI = o; o += al(L.gi_stash ? L.BT * L.Gp : 0);
   L.hq = (int)rup(L.H + 1, 16);
   L.st_hprev = o; o += al(L.g32tn ? L.BT * (size_t)L.hq : 0);     // [Hprev|1] with 16-byte aligned rows (exact fp32, large B*T)
@@ -672,7 +672,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
                                 loss, status, st);
     else   // register-resident recurrence: dGHn alone when the dW_hh GEMM has the two-source A operand; fused loss
       rc = launch_gru_bwd(d->B, d->T, d->H, p->w_hh, Y, fused_loss ? nullptr : dY, fused_loss ? labels : nullptr, gates,
-                          dGI, (int)L.Gp, L.dghn ? dGH : nullptr, L.dghn ? nullptr : dGH,
+                          sf + L.st_GI, (int)L.Gp, dGI, (int)L.Gp, L.dghn ? dGH : nullptr, L.dghn ? nullptr : dGH,
                           fused_loss ? sf + L.st_stats : nullptr, (int64_t)L.BT * L.H, grad_scale, loss, status, st);
     if (rc != WGNN_OK) return rc;
   }

@@ -217,7 +217,7 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* 
 //   backward: exactly one of dY / labels; dGI [B*T][ldd] and EITHER dGHn [B*T][gru_hn(H)] (dGH's r and z thirds equal
 //   dGI's) OR the full dGH [B*T][ldd]; stat_part (nullable, with labels): loss[0] is finalised from the forward's partials
 int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
-                   const float* gates, float* dGI, int ldd, float* dGHn, float* dGH, const float* stat_part,
+                   const float* gates, const float* GI /*forward's GI rows (stash): n is recomputed*/, int ldgi, float* dGI, int ldd, float* dGHn, float* dGH, const float* stat_part,
                    int64_t n_loss, float grad_scale, float* loss, unsigned* status, hipStream_t st);
 bool gru_shape_supported(int H);
 size_t gru_gates_floats(int B, int T, int H);

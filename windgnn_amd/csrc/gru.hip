@@ -103,7 +103,9 @@ __global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, 
   const float* Labw = Lab ? Lab + (size_t)b0 * T * H : nullptr;
   float* Hpw = hprev ? hprev + (size_t)b0 * T * hq : nullptr;
   const int NW = (H + 15) / 16;
-  f32x4* gatesw = gates ? (f32x4*)gates + ((size_t)blockIdx.x * T * NW + wave) * 4 * 64 + lane : nullptr;
+  // three components per record, r | z | gh_n: the BPTT kernel recomputes n = tanh(gi_n + r gh_n) from GI's n third, which
+  // stays in the stash (round 4, as in grux.hip: the recurrences are bound by their bytes)
+  f32x4* gatesw = gates ? (f32x4*)gates + ((size_t)blockIdx.x * T * NW + wave) * 3 * 64 + lane : nullptr;
   int rowt[4];            // (local window row) * T, clamped to the last valid window
   bool rowok[4];
 #pragma unroll
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, 
         // hardware exp2 / rcp forms (|error| < 3e-7, as in grux.hip and gru_small.hip)
         const float rg = sigmoid_fast(ar[r]);
         const float zg = sigmoid_fast(az[r]);
-        const float ng = tanh_fast(gi[2][r] + rg * an[r]);
+        const float ng = tanh_fast(__builtin_fmaf(rg, an[r], gi[2][r]));   // the BPTT kernel recomputes exactly this
         rg4[r] = rg; zg4[r] = zg; ng4[r] = ng;
         hnew[r] = (1.f - zg) * ng + zg * hold[r];
         if (rowok[r]) {
@@ -172,11 +174,10 @@ __global__ void __launch_bounds__(NTHREADS) gru_fwd_kernel(int B, int T, int H, 
         hold[r] = hnew[r];
       }
       if (gates) {
-        f32x4* rec = gatesw + (size_t)t * NW * 4 * 64;
+        f32x4* rec = gatesw + (size_t)t * NW * 3 * 64;
         rec[0] = rg4;
         rec[64] = zg4;
-        rec[128] = ng4;
-        rec[192] = an;
+        rec[128] = an;
       }
       if (jv) {
 #pragma unroll
@@ -225,7 +226,9 @@ template <int KS3>   // k steps of 4 over the gate-row index, 4 KS3 >= 3H, KS3 e
 __global__ void __launch_bounds__(NTHREADS) gru_bwd_kernel(int B, int T, int H, const float* __restrict__ Whh,
                                                            const float* __restrict__ Y, const float* __restrict__ dY,
                                                            const float* __restrict__ Lab,
-                                                           const float* __restrict__ gates, float* __restrict__ dGI,
+                                                           const float* __restrict__ gates,
+                                                           const float* __restrict__ GIn, int ldgi,
+                                                           float* __restrict__ dGI,
                                                            int ldd, float* __restrict__ dGN, int hn,
                                                            float* __restrict__ dGH /*nullable: full rows [B*T][ldd]*/,
                                                            const float* __restrict__ stat_part, int nstat, float inv_n,
@@ -280,7 +283,8 @@ __global__ void __launch_bounds__(NTHREADS) gru_bwd_kernel(int B, int T, int H, 
     WT[ks] = (jv && k < G3) ? Whh[(size_t)k * H + j] : 0.f;
   }
   const int NW = (H + 15) / 16;
-  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * 4 * 64 + lane;
+  const f32x4* gatesw = (const f32x4*)gates + ((size_t)blockIdx.x * T * NW + (active ? wave : 0)) * 3 * 64 + lane;
+  const float* GIw = GIn + (size_t)b0 * T * ldgi + 2 * H;          // n third of this workgroup's GI rows (stash)
   const float* Yw = Y + (size_t)b0 * T * H;
   const float* dYw = dY ? dY + (size_t)b0 * T * H : nullptr;
   const float* Labw = Lab ? Lab + (size_t)b0 * T * H : nullptr;
@@ -298,15 +302,15 @@ __global__ void __launch_bounds__(NTHREADS) gru_bwd_kernel(int B, int T, int H, 
   struct StepIn { float dy[4], r[4], z[4], n[4], ghn[4], hp[4]; };
   auto load_step = [&](int t, StepIn& s) {
     const int tc = t > 0 ? t : 0;
-    const f32x4* rec = gatesw + (size_t)tc * NW * 4 * 64;
-    const f32x4 r4 = rec[0], z4 = rec[64], n4 = rec[128], g4 = rec[192];
+    const f32x4* rec = gatesw + (size_t)tc * NW * 3 * 64;
+    const f32x4 r4 = rec[0], z4 = rec[64], g4 = rec[128];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int bt = rowt[r] + tc;
       s.dy[r] = Lab ? Labw[bt * H + jc] : dYw[bt * H + jc];       // the label, or dY itself
       s.r[r] = r4[r];
       s.z[r] = z4[r];
-      s.n[r] = n4[r];
+      s.n[r] = GIw[bt * ldgi + jc];                                // gi_n: n itself is formed in the step
       s.ghn[r] = g4[r];
       const float hp = Yw[(bt - (tc > 0 ? 1 : 0)) * H + jc];
       s.hp[r] = tc > 0 ? hp : 0.f;
@@ -332,7 +336,8 @@ __global__ void __launch_bounds__(NTHREADS) gru_bwd_kernel(int B, int T, int H, 
         const int m = 4 * lk + r;
         const float dyv = Lab ? (ycur[r] - cur.dy[r]) * coef_lab : cur.dy[r];
         const float dh = rowok[r] ? dyv + dhn[r] : 0.f;
-        const float rg = cur.r[r], zg = cur.z[r], ng = cur.n[r];
+        const float rg = cur.r[r], zg = cur.z[r];
+        const float ng = tanh_fast(__builtin_fmaf(rg, cur.ghn[r], cur.n[r]));   // the forward's n, bit for bit
         const float dn = dh * (1.f - zg);
         const float dz = dh * (cur.hp[r] - ng);
         const float dnt = dn * (1.f - ng * ng);
@@ -418,7 +423,7 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* 
   const double bt = (double)B * T;
   const double fl = bt * 2.0 * 3 * H * H;
   const double by = bt * 4.0 * (3 * H + (last_only ? 0 : H) + (labels ? H : 0) + (hprev ? hq : 0)) +
-                    (gates ? 4.0 * gate_floats(B, T, H) : 0.0);
+                    (gates ? 3.0 * gate_floats(B, T, H) : 0.0);     // three of the buffer's four components are used
 #define FCASE(K)                                                                                                  \
   case K:                                                                                                         \
     PROF_LAUNCH("gru_fwd_kernel<" #K ">", fl, by, st,                                                             \
@@ -437,21 +442,23 @@ int launch_gru_fwd(int B, int T, int H, const float* GI, int ldgi, const float* 
 // exactly one of dY / labels is non-null.  labels: dY = (Y - labels) * 2 grad_scale / n_loss is formed in the kernel;
 // with stat_part (the forward's partial sums + tag) workgroup 0 also writes loss[0] = mean((Y - labels)^2).
 int launch_gru_bwd(int B, int T, int H, const float* Whh, const float* Y, const float* dY, const float* labels,
-                   const float* gates, float* dGI, int ldd, float* dGHn, float* dGH, const float* stat_part,
+                   const float* gates, const float* GI /*the forward's GI rows [B*T][ldgi] (stash)*/, int ldgi, float* dGI, int ldd, float* dGHn, float* dGH, const float* stat_part,
                    int64_t n_loss, float grad_scale, float* loss, unsigned* status, hipStream_t st) {
   if (!gru_shape_supported(H)) return WGNN_ERR_UNSUPPORTED;
   if ((dY == nullptr) == (labels == nullptr) || ldd < 3 * H || (dGHn == nullptr) == (dGH == nullptr)) return WGNN_ERR_SHAPE;
   if (stat_part && (!labels || !loss)) return WGNN_ERR_NULL;
+  if (!GI || ldgi < 3 * H) return WGNN_ERR_NULL;
   const int ks3 = pick_ks(cdiv_i(3 * H, 4), BWD_KS3, (int)(sizeof(BWD_KS3) / sizeof(int)));
   const int hn = gru_hn(H);
   const float inv_n = 1.0f / (float)n_loss, coef = 2.0f * grad_scale / (float)n_loss;
   const double bt = (double)B * T;
-  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (H + H + 3 * H + (dGH ? 3 * H : H)) + 4.0 * gate_floats(B, T, H);
+  const double fl = bt * 2.0 * 3 * H * H, by = bt * 4.0 * (H + H + 3 * H + (dGH ? 3 * H : H)) + 3.0 * gate_floats(B, T, H) +
+                                          bt * 4.0 * H;   // + GI's n third
 #define BCASE(K)                                                                                                  \
   case K:                                                                                                         \
     PROF_LAUNCH("gru_bwd_kernel<" #K ">", fl, by, st,                                                             \
                 hipLaunchKernelGGL(gru_bwd_kernel<K>, dim3(cdiv_i(B, MB)), dim3(NTHREADS), 0, st, B, T, H, Whh, Y, dY,  \
-                                   labels, gates, dGI, ldd, dGHn, hn, dGH, stat_part, gru_blocks(B), inv_n, coef,  \
+                                   labels, gates, GI, ldgi, dGI, ldd, dGHn, hn, dGH, stat_part, gru_blocks(B), inv_n, coef,  \
                                    loss, status));                                                                      \
     break
   switch (ks3) {
