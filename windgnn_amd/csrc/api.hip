@@ -229,7 +229,7 @@ void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float
 //   unset / "1"  forwards WITHOUT a stash (inference: wgnn_fwd(stash = NULL), wgnn_fwd_last) -- where it measured faster
 //                (B = 4096: f16x3 238 -> 215 us, f16 + bf16 I/O 149 -> 139 us; no g plane reaches HBM);
 //   "2"          every forward it supports, training too (there the stash copy of g makes it slower: 742 -> 770 us per step
-//                in f16x3, 522 -> 527 in f16: DESIGN.md section 5, round 4);
+//                in f16x3, 514.5 -> 514.4 in f16: DESIGN.md section 5, round 4);
 //   "0"          never.  The results are bit-identical either way (tests/test_gpu_parity.py).
 int fused_fwd_mode() {
   const char* e = getenv("WGNN_FUSED_FWD");
