@@ -108,6 +108,20 @@ class DirectRccl:
                 lib.ncclCommDestroy(comm)
             return
         self._lib, self.comm = lib, comm
+        # known-answer check of the new communicator before any gradient goes through it: [1, rank + 1] must sum to
+        # [world, world (world + 1) / 2] on every rank, else every rank drops back to torch.distributed's own collective
+        probe = torch.tensor([1.0, float(rank + 1), 0.0, 0.0], dtype=torch.float32, device=device)
+        try:
+            self.all_reduce_(probe)
+            got = probe.cpu().tolist()
+            fine = int(got[0] == float(world) and got[1] == world * (world + 1) / 2.0)
+        except RuntimeError:
+            fine = 0
+        good.fill_(fine)
+        dist.all_reduce(good, op=dist.ReduceOp.MIN, group=group)
+        if int(good.item()) == 0:
+            lib.ncclCommDestroy(comm)
+            self._lib, self.comm = None, None
 
     def all_reduce_(self, t: torch.Tensor) -> None:
         """In-place fp32 sum over the ranks, enqueued on the current stream of t's device."""
