@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwindgnn_hip.so")
+# WGNN_LIB: another build of the SAME library (same-box A/B timing of kernel variants, tools/exp); never a different backend
+LIB_PATH = os.environ.get("WGNN_LIB") or os.path.join(_HERE, "csrc", "libwindgnn_hip.so")
 
 MATH_F32 = 0
 MATH_F16X3 = 1

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
                                                             int write_lo) {
   // write_lo == 0 (X3, large B*T): dGI / dGHn leave the chip as ONE fp16 plane (the lo halves stay in LDS, where the
   // recurrence's own product dgh W_hh uses them): the three GEMMs that consume them run two passes
-  constexpr int DS = 32 * KSB + 8;
+  constexpr int DS = 32 * KSB + 24;   // row stride in halfs: odd in 16-byte units (conflict-free b128 rows); 8 zero pad halfs, then 8 dump halfs
   // stat_part != null (wgnn_bwd_mse_part(.. | 8) after wgnn_fwd_loss): the loss, the power-of-two range scale and the dY
   // coefficient are finalised HERE from the forward recurrence's nstat partial pairs (sum | max), by every workgroup for
   // itself (2 nstat floats out of L2; the max is order-independent, so all workgroups agree on the scale), instead of in a
@@ -650,6 +650,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
     }
   }
   f32x4 dhn = {0.f, 0.f, 0.f, 0.f};
+  // columns of this lane's unit in the dgh row (r | z | pad | n r) and the dgi row (r | z | n); lanes past H: the dump halfs
+  const int o_pad = 32 * KSB + 8 + (c & 7);
+  const int o_r = jv ? j : o_pad, o_z = jv ? H + j : o_pad, o_n = jv ? MS + j : o_pad, o_t = jv ? 2 * H + j : o_pad;
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
@@ -678,17 +681,24 @@ __global__ void __launch_bounds__(NTHREADS) grux_bwd_kernel(int B, int T, int H,
         const float daz = dz * zg * (1.f - zg);
         const float dnr = dnt * rg;
         acc[r] = dh * zg;
-        if (jv) {
-          put_split<X3>(dhi, dlo, m * DS + j, dar);
-          put_split<X3>(dhi, dlo, m * DS + H + j, daz);
-          put_split<X3>(dhi, dlo, m * DS + MS + j, dnr);
-          ihi[m * DS + j] = dhi[m * DS + j];
-          ihi[m * DS + H + j] = dhi[m * DS + H + j];
-          if (X3) {
-            ilo[m * DS + j] = dlo[m * DS + j];
-            ilo[m * DS + H + j] = dlo[m * DS + H + j];
-          }
-          put_split<X3>(ihi, ilo, m * DS + 2 * H + j, dnt);
+        // No branch on jv and no read-back: lanes past H aim at the row's 8 dump halfs (never read as K, never copied out),
+        // so the four rows' chains sit in one basic block, and dar / daz go to both tiles from registers (the former
+        // `ihi[..] = dhi[..]` copies were 16 serialized LDS round trips per step): 101.2 -> 97.5 us (r4, same box)
+        const _Float16 arh = (_Float16)dar, azh = (_Float16)daz, nrh = (_Float16)dnr, nth = (_Float16)dnt;
+        dhi[m * DS + o_r] = arh;
+        dhi[m * DS + o_z] = azh;
+        dhi[m * DS + o_n] = nrh;
+        ihi[m * DS + o_r] = arh;
+        ihi[m * DS + o_z] = azh;
+        ihi[m * DS + o_t] = nth;
+        if (X3) {
+          const _Float16 arl = (_Float16)(dar - (float)arh), azl = (_Float16)(daz - (float)azh);
+          dlo[m * DS + o_r] = arl;
+          dlo[m * DS + o_z] = azl;
+          dlo[m * DS + o_n] = (_Float16)(dnr - (float)nrh);
+          ilo[m * DS + o_r] = arl;
+          ilo[m * DS + o_z] = azl;
+          ilo[m * DS + o_t] = (_Float16)(dnt - (float)nth);
         }
       }
     }
