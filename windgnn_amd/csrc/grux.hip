@@ -282,12 +282,16 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
       }
       f32x4 rg4, zg4, ng4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float rg = sigmoid_fast(ar[r]);
+      for (int r = 0; r < 4; ++r) {                      // the four rows' gate chains in ONE basic block (they interleave);
+        const float rg = sigmoid_fast(ar[r]);            // everything conditional comes in the loop below
         const float zg = sigmoid_fast(az[r]);
         const float ng = tanh_fast(__builtin_fmaf(rg, an[r], gi[2][r]));   // the BPTT kernel recomputes exactly this
         rg4[r] = rg; zg4[r] = zg; ng4[r] = ng;
         hnew[r] = (1.f - zg) * ng + zg * hold[r];
+        hold[r] = hnew[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
         if (IO) {
           if (jv) yt[(4 * g + r) * HY + j] = hnew[r];   // -> Y through the row copy-out below
         } else if (rowok[r]) {
@@ -299,7 +303,6 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
           ssum = fmaf(dl, dl, ssum);
           smax = fmaxf(smax, fabsf(dl));
         }
-        hold[r] = hnew[r];
       }
       if (gates) {
         f32x4* rec = gatesw + (size_t)t * NW * GREC * 64;
@@ -325,9 +328,9 @@ __global__ void __launch_bounds__(NTHREADS) grux_fwd_kernel(int B, int T, int H,
         }
       }
     }
-    if (active && jv) {
+    if (active) {                                    // lanes past H aim at the row's pad halfs (never read as K, never copied out)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) put_split<X3>(nhi, nlo, (4 * g + r) * HS + j, hnew[r]);
+      for (int r = 0; r < 4; ++r) put_split<X3>(nhi, nlo, (4 * g + r) * HS + (jv ? j : HP + (c & 7)), hnew[r]);
     }
     stage_lab(t + 1);                              // other parity than the labels read above
     __syncthreads();                               // h_t complete; everyone is done reading h_{t-1}
