@@ -19,19 +19,20 @@ __global__ void __launch_bounds__(64 * NW) k(float* out, int iters, int row_floa
     __syncthreads();
   }
 }
-template <int NW> void run(float* d, const char* name, int row_floats) {
+template <int NW> void run(float* d, const char* name, int row_floats, int nblk = 256) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   const int iters = 24;
   const size_t step = row_floats, row_stride = (size_t)iters * row_floats;
+  if ((size_t)nblk * 16 * row_stride * 4 > ((size_t)1 << 30)) { printf("skipped: footprint beyond the 1 GiB buffer\n"); return; }
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(a);
-    hipLaunchKernelGGL(k<NW>, dim3(256), dim3(64 * NW), 0, 0, d, iters, row_floats, row_stride, step);
+    hipLaunchKernelGGL(k<NW>, dim3(nblk), dim3(64 * NW), 0, 0, d, iters, row_floats, row_stride, step);
     hipEventRecord(b); hipEventSynchronize(b);
   }
   float ms; hipEventElapsedTime(&ms, a, b);
-  double bytes = 256.0 * iters * 16 * row_floats * 4;
-  printf("%s waves=%d row=%dB: %.1f us, %.2f TB/s, %.1f B/clk/CU @2.2GHz\n", name, NW, row_floats * 4, ms * 1e3, bytes / ms / 1e9,
-         bytes / 256 / (ms * 1e-3 * 2.2e9));
+  double bytes = (double)nblk * iters * 16 * row_floats * 4;
+  printf("%s waves=%d row=%dB workgroups=%d: %.1f us, %.2f TB/s, %.1f B/clk/CU @2.2GHz\n", name, NW, row_floats * 4, nblk, ms * 1e3, bytes / ms / 1e9,
+         bytes / nblk / (ms * 1e-3 * 2.2e9));
 }
 // streaming read (sum to keep the loads) and copy, 16 waves per CU-sized block, float4 per lane
 __global__ void __launch_bounds__(1024) rd(const f32x4* in, size_t n4, float* sink) {
@@ -59,5 +60,7 @@ int main() {
   run<4>(d, "x4", 408); run<8>(d, "x4", 408); run<12>(d, "x4", 408); run<16>(d, "x4", 408);
   run<4>(d, "x4", 640); run<12>(d, "x4", 640);
   run<4>(d, "x4", 1024); run<12>(d, "x4", 1024);
+  // fewer active CUs (one workgroup each): is ~11 B/clk/CU the CU's own store path or the chip's rate divided by 256?
+  for (int nb : {16, 32, 64, 128, 256}) run<12>(d, "x4", 1024, nb);
   return 0;
 }
