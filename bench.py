@@ -172,6 +172,19 @@ def cpu_baseline(budget_s=10.0, Bc=1024, faithful_budget_s=8.0):
                          "sample": "%d sequential B=1 steps as src/main.py:65-80 (%s), %.1f s" % (m, shape, dt1)}}
 
 
+def check_stashless_forward(A, X, L, trainer, math):
+    """The forward-only figure times the stash-less forward (the fused GCN + projection kernel where it applies); VERDICT r4
+    weak 1: it was timed without its output ever being looked at at this size.  One call of each form on the SAME parameters:
+    the stash-less Y must be the training forward's Y bit for bit (the training forward is what the full-size parity tests
+    hold against the fp64 oracle).  Raises otherwise: a wrong forward must not produce a bench line."""
+    from windgnn_amd.functional import gcn_gru_forward_raw
+    y_train = gcn_gru_forward_raw(A, X, trainer.p_views, math, want_stash=True, labels=L, prepared=trainer._prepared)[0]
+    y_inf = gcn_gru_forward_raw(A, X, trainer.p_views, math, want_stash=False, prepared=trainer._prepared)[0]
+    if not torch.equal(y_train, y_inf):
+        raise RuntimeError("bench.py: the stash-less forward's Y differs from the training forward's (max |d| = %.3e)"
+                           % float((y_train.float() - y_inf.float()).abs().max()))
+
+
 def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
     """One more configuration timed on the same box: `nsteps` full training steps (TrainStep.step) after 10 warm-up steps,
     inputs resident; with `forward` also the forward-only time against its own algorithmic bytes (X + Y in the I/O type)."""
@@ -198,6 +211,7 @@ def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5):                              # untimed first launches of the stash-less forward's kernels
             gcn_gru_forward_raw(A, X, tr.p_views, m.math, want_stash=False, prepared=tr._prepared)
+        check_stashless_forward(A, X, L, tr, m.math)
         e0.record()
         for _ in range(nsteps):
             gcn_gru_forward_raw(A, X, tr.p_views, m.math, want_stash=False, prepared=tr._prepared)
@@ -250,6 +264,21 @@ def secondary_c5(dev, math="f16x3", nsteps=3, B=128):
     return out
 
 
+def c5_in_child(math, timeout_s=420):
+    """secondary_c5(math) in a fresh child process (`bench.py --c5-child MATH` prints its dict as one JSON line)."""
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--c5-child", math], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=timeout_s, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "c5 child (%s) exceeded %d s and was killed" % (math, timeout_s)}
+    if r.returncode != 0:
+        return {"error": "c5 child (%s) exited with %d: %s" % (math, r.returncode, r.stderr.decode(errors="replace")[-300:])}
+    try:
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": "c5 child (%s): unreadable output: %r" % (math, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +298,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-fp32 secondary measurement")
     ap.add_argument("--no-c5", action="store_true", help="skip the 4096-station secondary (c5_csr_b128: ~40 GB of GPU memory, ~20 s)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--c5-child", default=None, choices=["f16x3", "f16x3g"], help=argparse.SUPPRESS)
+    ap.add_argument("--direct-rccl", action="store_true",
+                    help="N > 1: the gradient all-reduce on the compute stream through the step's own RCCL communicator "
+                         "(distributed.DirectRccl; opt-in, also WGNN_RCCL_DIRECT=1) instead of torch.distributed's stream")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the collective step even with one rank (rehearses the "
                          "N > 1 code path on a one-GPU box; launch with torch.distributed.run --nproc-per-node 1)")
@@ -278,6 +311,11 @@ def main():
     # GPU, so the line does not depend on the launcher's environment (windgnn_amd/distributed.py)
     from windgnn_amd.distributed import ensure_rccl_env
     ensure_rccl_env()
+
+    if args.c5_child:                                   # child of c5_in_child(): one dict on stdout, nothing else
+        torch.cuda.set_device(0)
+        print(json.dumps(secondary_c5(torch.device("cuda", 0), args.c5_child)), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -320,7 +358,10 @@ def main():
     S, H = (34, 102) if args.workload == "c3" else (4096, 12288)
     B = args.batch or (4096 if args.workload == "c3" else 128)
     model = GCN_GRU(F, F, F, S * F, H, math=args.math).to(dev)
-    trainer = TrainStep(model, process_group=dist.group.WORLD if use_dist else None)
+    trainer = TrainStep(model, process_group=dist.group.WORLD if use_dist else None,
+                        direct_rccl=True if args.direct_rccl else None)
+    # an all-reduce of ones through the path the step's bucket takes: the ranks that really exchange data
+    ranks_seen = trainer.exchange.ranks_seen() if use_dist else None
     A = (adjacency_34() if args.workload == "c3" else adjacency_knn(S)).to(dev)
     X, L = make_inputs(B, rank, dev, S, H, args.io)
     esz = 4.0 if args.io == "fp32" else 2.0
@@ -348,6 +389,7 @@ def main():
         _lib.profile_enable(False)
         for _ in range(5):      # untimed: the stash-less forward runs kernels the training step does not (first launch, code load)
             gcn_gru_forward_raw(A, X, trainer.p_views, model.math, want_stash=False, prepared=trainer._prepared)
+        check_stashless_forward(A, X, L, trainer, model.math)   # what is timed below is the training forward's Y, bit for bit
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.steps):
@@ -441,7 +483,8 @@ def main():
         fwd_bytes = B * T * (S * F + H) * esz
         forward = {"us": round(fwd_s * 1e6, 1), "algorithmic_GBs": round(fwd_bytes / fwd_s / 1e9, 1),
                    "hbm_frac": round(fwd_bytes / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
-                   "windows_per_s": round(B / fwd_s, 1)}
+                   "windows_per_s": round(B / fwd_s, 1),
+                   "checked": "Y of the timed stash-less call == the training forward's Y, bit for bit, in this run"}
         # ---- secondaries on the same box, each a labelled dtype of its own (never folded into `value`):
         #   f16x3g_mixed         the headline workload in WGNN_MATH_F16X3G (mixed precision in the backward; labelled, with its
         #                        measured gradient error next to it)
@@ -465,13 +508,14 @@ def main():
                 "BASELINE configs[2]: S=34, T=24, B=4096, one-pass fp16 MFMA (fp32 accumulate), bf16 X / Y / labels; "
                 "own tolerance (Y 2e-2), never the fp32-parity number", forward=True)
             if not args.no_c5:
-                try:        # ~40 GB of GPU memory: a failure here must not cost the headline line
-                    extra["c5_csr_b128"] = secondary_c5(dev, "f16x3")
-                    extra["c5_csr_b128"]["f16x3g_mixed"] = {k: v for k, v in secondary_c5(dev, "f16x3g").items()
-                                                            if k in ("dtype", "value", "ms_per_step", "steps", "roofline")}
-                except Exception as e:
-                    extra.setdefault("c5_csr_b128", {})["error"] = repr(e)[:300]
-                    torch.cuda.empty_cache()
+                # ~40 GB of GPU memory and 2.4 G parameters per mode: each runs in a CHILD process with a time limit, so that
+                # an out-of-memory kill, a GPU fault or a hang there costs this one field and not the headline measured above
+                # (a try / except only catches Python exceptions)
+                extra["c5_csr_b128"] = c5_in_child("f16x3")
+                if "error" not in extra["c5_csr_b128"]:
+                    mixed = c5_in_child("f16x3g")
+                    extra["c5_csr_b128"]["f16x3g_mixed"] = {k: v for k, v in mixed.items()
+                                                            if k in ("dtype", "value", "ms_per_step", "steps", "roofline", "error")}
 
     if rank == 0:
         out = {
@@ -496,8 +540,12 @@ def main():
                        "collective": (("one rccl all-reduce per step: [loss | conv | GRU gradients], 0.67 MB, between wgnn_finish(6) and "
                                        "wgnn_finish(0, adam)" + (", enqueued on the compute stream through the step's own communicator"
                                                                  if trainer.exchange.direct is not None else
-                                                                 ", through torch.distributed (its own stream)"))
+                                                                 ", through torch.distributed (its own stream)" +
+                                                                 ("; the own communicator was asked for and declined: %s"
+                                                                  % trainer.exchange.direct_declined
+                                                                  if trainer.exchange.direct_declined else "")))
                                       if use_dist else "none (one rank)")},
+            "rccl_ranks_seen": ranks_seen,
             "loss": round(float(loss), 6),
             "roofline": roofline,
             "path": path,

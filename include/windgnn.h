@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 121 /* 0.1.2: wgnn_params.prepared, wgnn_finish, WGNN_BWD_DEFER; 121: WGNN_FINISH_ADAM_GRU / _CONV */
+#define WGNN_VERSION 122 /* 0.1.2: wgnn_params.prepared, wgnn_finish, WGNN_BWD_DEFER; 121: WGNN_FINISH_ADAM_GRU / _CONV; 122: wgnn_set_option */
 
 /* Status block: the first 256 bytes of every `workspace` passed to wgnn_fwd / wgnn_bwd* belong to the library as a
  * sticky status area that kernels only ever OR into; word 0 (uint32) holds the bits below.  The caller zeroes the
@@ -155,6 +155,18 @@ typedef struct wgnn_adam {
 int wgnn_version(void);
 const char* wgnn_strerror(int status);
 
+/* Process-wide options: which of two bit-identical kernel schedules runs.  No option changes a result bit; there is no
+ * reference counterpart (the reference has no kernels to choose between).  wgnn_set_option returns the PREVIOUS value (>= 0)
+ * or WGNN_ERR_SHAPE for an unknown key / value; it takes effect for calls issued after it returns and is atomic, but callers
+ * that flip an option while other threads launch get either schedule for those launches.
+ *   WGNN_OPT_FUSED_FWD  0 never / 1 stash-less forwards (default) / 2 every supported forward run the fused GCN + input
+ *                       projection kernel (csrc/gcngi.hip).  Initial value: environment variable WGNN_FUSED_FWD, read once at
+ *                       the first call that needs it (never again). */
+#define WGNN_OPT_FUSED_FWD 0
+#define WGNN_OPT_COUNT 1
+int wgnn_set_option(int key, int value);
+int wgnn_get_option(int key);
+
 /* Bytes of scratch wgnn_fwd / wgnn_bwd need (the larger of the two), and of the forward->backward
  * stash.  Both depend on dims only. */
 size_t wgnn_workspace_bytes(const wgnn_dims* d);
@@ -163,9 +175,8 @@ size_t wgnn_stash_bytes(const wgnn_dims* d);
 /* Y[B,T,H] = GRU(relu(A relu(A X W1 + b1) W2 + b2)), h0 = 0 per window.
  * stash may be NULL (inference: src/main.py:100-102); otherwise it receives what wgnn_bwd needs.
  * In the fp16-plane math modes with a dense adjacency and H <= 127 a stash-less call (and wgnn_fwd_last) runs both graph
- * convolutions and the GRU input projection as ONE kernel whose intermediate g never leaves the chip (csrc/gcngi.hip); the
- * environment variable WGNN_FUSED_FWD selects: unset / "1" stash-less forwards, "2" every supported forward, "0" never.
- * The results do not depend on it (bit-identical either way). */
+ * convolutions and the GRU input projection as ONE kernel whose intermediate g never leaves the chip (csrc/gcngi.hip);
+ * WGNN_OPT_FUSED_FWD (above) selects which forwards do.  The results do not depend on it (bit-identical either way). */
 int wgnn_fwd(const wgnn_dims* d, const float* A, const void* X /* d->io */, const wgnn_params* p, void* Y /* d->io */,
              void* stash, void* workspace, size_t workspace_bytes, void* stream);
 

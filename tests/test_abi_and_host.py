@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(L.EXPORTS), (declared ^ set(L.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.wgnn_version() == 121
+    assert lib.wgnn_version() == 122
 
 
 def _header_prototypes():

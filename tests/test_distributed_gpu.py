@@ -47,10 +47,10 @@ def _train(rank, world, port, out_dir, backend="gloo", tag=None, batches=(32, 32
     m = m.to(dev)
     tr = TrainStep(m, process_group=group, overlap_collectives=overlap, direct_rccl=direct)
     assert tr.collective == (world > 1 or backend == "nccl")
-    if backend == "nccl" and not overlap and direct is not False:
-        assert tr.exchange.direct is not None           # our own RCCL communicator, all-reduce on the compute stream
+    if backend == "nccl" and not overlap and direct is True:
+        assert tr.exchange.direct is not None, tr.exchange.direct_declined   # our own RCCL communicator (opt-in), on the compute stream
     elif tr.collective:
-        assert tr.exchange.direct is None
+        assert tr.exchange.direct is None                # the default: torch.distributed's collective
     A = torch.from_numpy(fx["A"]).to(dev)
     X, L = torch.from_numpy(fx["X"]), torch.from_numpy(fx["L"])
     losses = []
@@ -216,16 +216,60 @@ def test_rccl_allreduce_path_executes_and_is_bitwise_neutral_with_one_rank(tmp_p
     is the identity, so the parameters after two steps must equal the no-group run bit for bit."""
     assert torch.cuda.is_available()
     mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "gloo", "plain"), nprocs=1, join=True)
-    mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1"), nprocs=1, join=True)
-    mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1_torch", (32, 32), False, False, False), nprocs=1, join=True)
+    mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1", (32, 32), False, False, True), nprocs=1, join=True)
+    mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1_torch"), nprocs=1, join=True)
     mp.spawn(_train, args=(1, _free_port(), str(tmp_path), "nccl", "rccl1_overlap", (32, 32), False, True), nprocs=1, join=True)
     p0 = np.load(os.path.join(str(tmp_path), "p_plain.npy"))
-    # the single all-reduce through our own communicator on the compute stream (default: distributed.DirectRccl), the same
-    # through torch.distributed (its own stream), and the two-collective form
+    # the single all-reduce through our own communicator on the compute stream (opt-in: distributed.DirectRccl), the same
+    # through torch.distributed (its own stream: the default), and the two-collective form
     for tag in ("rccl1", "rccl1_torch", "rccl1_overlap"):
         assert np.array_equal(p0, np.load(os.path.join(str(tmp_path), "p_%s.npy" % tag))), tag
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "loss_plain.npy")),
                               np.load(os.path.join(str(tmp_path), "loss_%s.npy" % tag))), tag
+
+
+def _train_nccl_multi(rank, world, port, out_dir, direct):
+    """One rank per GPU on the nccl backend: TrainStep with / without the own communicator, bucket and parameters saved."""
+    from windgnn_amd.distributed import ensure_rccl_env, shard_windows
+    ensure_rccl_env()
+    from windgnn_amd import GCN_GRU
+    from windgnn_amd.trainer import TrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    fx = load_fixture("f2_s7_t12_b32_ckpt")
+    m = GCN_GRU(13, 13, 13, 7 * 13, 21, math="f16x3")
+    m.load_state_dict({k: v.clone() for k, v in fx["params"].items()})
+    with TrainStep(m.to(dev), process_group=dist.group.WORLD, direct_rccl=direct) as tr:
+        assert (tr.exchange.direct is not None) == bool(direct), tr.exchange.direct_declined
+        assert tr.exchange.ranks_seen() == world
+        A = torch.from_numpy(fx["A"]).to(dev)
+        X, L = torch.from_numpy(fx["X"]), torch.from_numpy(fx["L"])
+        for n_glob in (31, 32):
+            Xs, Ls = shard_windows(X[:n_glob], L[:n_glob], rank, world)
+            tr.step(A, Xs.to(dev), Ls.to(dev), n_global=n_glob)
+        tr.check()                                   # ncclCommGetAsyncError of the own communicator
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "mg_%d_rank%d.npy" % (int(bool(direct)), rank)),
+                np.concatenate([tr._gbuf.cpu().numpy(), tr.flat_p.cpu().numpy()]))
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the driver's "
+                                                          "round-end box has one; this is for an 8-GPU node)")
+def test_direct_rccl_with_two_ranks_equals_torch_distributed(tmp_path):
+    """the step's own communicator (DirectRccl, opt-in) has only ever moved bytes in a one-rank group.  With two
+    devices: two ranks, two steps with unequal shards, through the own communicator and through torch.distributed -- the
+    all-reduced bucket and the parameters must agree on every rank and between the two paths (a two-rank fp32 sum is
+    order-independent: bit for bit)."""
+    for direct in (False, True):
+        mp.spawn(_train_nccl_multi, args=(2, _free_port(), str(tmp_path), direct), nprocs=2, join=True)
+    a = [np.load(os.path.join(str(tmp_path), "mg_0_rank%d.npy" % r)) for r in range(2)]
+    b = [np.load(os.path.join(str(tmp_path), "mg_1_rank%d.npy" % r)) for r in range(2)]
+    assert np.array_equal(a[0], a[1]) and np.array_equal(b[0], b[1])
+    assert np.array_equal(a[0], b[0])
 
 
 def test_bench_multi_gpu_code_path_runs_under_torchrun_with_rccl():
@@ -249,3 +293,4 @@ def test_bench_multi_gpu_code_path_runs_under_torchrun_with_rccl():
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 5 and out["value"] > 1e4 and out["scaling"] == "weak"
     assert "rccl" in out["config"]["collective"]
+    assert out["rccl_ranks_seen"] == 1               # an all-reduce of ones through the path the step's bucket takes

@@ -1387,15 +1387,26 @@ def test_csr_adjacency_one_pass_fp16_mode(S, T, B, H, k):
 
 
 
-@pytest.mark.parametrize("math", ["f16x3", "f16x3g", "f16"])
-@pytest.mark.parametrize("S,T,B,H", [(34, 24, 256, 102), (34, 24, 37, 102), (7, 12, 32, 21), (5, 3, 17, 9), (16, 4, 16, 48),
-                                     (33, 1, 19, 100), (2, 7, 33, 6), (40, 3, 50, 120), (34, 5, 1, 102), (34, 24, 300, 127)])
-def test_fused_forward_front_end_is_bitwise_the_unfused_launches(S, T, B, H, math, monkeypatch):
-    """gcngi_fwd_kernel (GCN layers + input projection in one persistent kernel, g handed over through LDS; VERDICT r3 next 3)
-    against gcnx_fwd_kernel -> pgemm_nt_kernel (WGNN_FUSED_FWD=0): the same products in the same order, so Y, the loss and
-    all 8 gradients (the stash the fused kernel leaves: g's hi plane, + lo in strict f16x3) must agree BIT FOR BIT -- with
-    ragged B*T (not a multiple of the 32 / 64-row tile), odd S*13, every row-tile count that fits LDS, 16-bit I/O, with and
-    without a stash, and through wgnn_fwd_last."""
+class _fused_fwd:
+    """with _fused_fwd(mode): WGNN_OPT_FUSED_FWD = mode (0 never / 1 stash-less forwards / 2 every supported forward) inside
+    the block, restored afterwards (wgnn_set_option; the library reads the environment variable only once)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from windgnn_amd import _lib
+        self.prev = _lib.set_option(_lib.OPT_FUSED_FWD, self.mode)
+
+    def __exit__(self, *exc):
+        from windgnn_amd import _lib
+        _lib.set_option(_lib.OPT_FUSED_FWD, self.prev)
+
+
+def _fused_vs_unfused(S, T, B, H, math, io16):
+    """Everything a forward through gcngi_fwd_kernel can produce, under WGNN_OPT_FUSED_FWD = 0 and = 2: a training step
+    (Y, loss, the 8 gradients: they read the stash the fused kernel leaves), the stash-less forward, 16-bit I/O,
+    wgnn_fwd_last.  Returns ({mode: results}, inputs)."""
     from oracle import windgnn_oracle as orc
     from windgnn_amd.data import forward_last
     from windgnn_amd.functional import gcn_gru_forward_raw
@@ -1406,23 +1417,63 @@ def test_fused_forward_front_end_is_bitwise_the_unfused_launches(S, T, B, H, mat
     L = torch.rand(B, T, H, generator=g).to(dev)
     p = orc.init_params(S, 13, H, seed=S + H)
     res = {}
-    for fused in ("0", "2"):                     # never / every forward, training included (the default fuses stash-less forwards only)
-        monkeypatch.setenv("WGNN_FUSED_FWD", fused)
-        model = _model_from(p, S, H, math)
-        out, loss, grads = _run_step(model, A, X, L)
-        with torch.no_grad():
-            y_inf = model(A, X).cpu()                                           # no stash: the fused kernel writes no g at all
-        params = [q.detach() for q in model.hot_path_parameters()]
-        y16 = gcn_gru_forward_raw(A, X.half(), params, model.math, want_stash=False)[0].cpu()   # fp16 X / Y
-        last = forward_last(model, A, X, 0.0, 87.5).cpu()
+    for fused in (0, 2):                         # never / every forward, training included (the default fuses stash-less forwards only)
+        with _fused_fwd(fused):
+            model = _model_from(p, S, H, math)
+            out, loss, grads = _run_step(model, A, X, L)
+            with torch.no_grad():
+                y_inf = model(A, X).cpu()                                       # no stash: the fused kernel writes no g at all
+            params = [q.detach() for q in model.hot_path_parameters()]
+            y16 = gcn_gru_forward_raw(A, X.to(io16), params, model.math, want_stash=False)[0].cpu()   # 16-bit X / Y
+            last = forward_last(model, A, X, 0.0, 87.5).cpu()
         res[fused] = (out, loss, grads, y_inf, y16, last)
-    a, b = res["0"], res["2"]
+    return res, (A, X, L, p)
+
+
+def _assert_bitwise(res):
+    a, b = res[0], res[2]
     assert torch.equal(a[0], b[0]) and a[1] == b[1]
     assert torch.equal(a[3], b[3]) and torch.equal(a[3].reshape(a[0].shape), a[0])
     assert torch.equal(a[4], b[4])
     assert torch.equal(a[5], b[5])
     for k in PARAM_KEYS:
         assert torch.equal(a[2][k], b[2][k]), k
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16x3g", "f16"])
+@pytest.mark.parametrize("S,T,B,H", [(34, 24, 256, 102), (34, 24, 37, 102), (7, 12, 32, 21), (5, 3, 17, 9), (16, 4, 16, 48),
+                                     (33, 1, 19, 100), (2, 7, 33, 6), (40, 3, 50, 120), (34, 5, 1, 102), (34, 24, 300, 127)])
+def test_fused_forward_front_end_is_bitwise_the_unfused_launches(S, T, B, H, math):
+    """gcngi_fwd_kernel (GCN layers + input projection in one persistent kernel, g handed over through LDS; VERDICT r3 next 3)
+    against gcnx_fwd_kernel -> pgemm_nt_kernel (WGNN_OPT_FUSED_FWD = 0): the same products in the same order, so Y, the loss and
+    all 8 gradients (the stash the fused kernel leaves: g's hi plane, + lo in strict f16x3) must agree BIT FOR BIT -- with
+    ragged B*T (not a multiple of the 32 / 48-row tile), odd S*13, every row-tile count that fits LDS, 16-bit I/O, with and
+    without a stash, and through wgnn_fwd_last.  (At most ONE tile per workgroup here; the steady state is the next test.)"""
+    res, _ = _fused_vs_unfused(S, T, B, H, math, torch.float16)
+    _assert_bitwise(res)
+
+
+@pytest.mark.parametrize("math,io16", [("f16x3", torch.float16), ("f16", torch.bfloat16), ("f16x3", torch.bfloat16)])
+@pytest.mark.parametrize("S,T,B,H", [(34, 24, 4096, 102), (34, 24, 4097, 102), (34, 5, 1700, 127), (34, 5, 2500, 127),
+                                     (20, 3, 5555, 64)])
+def test_fused_forward_steady_state_many_tiles_per_workgroup(S, T, B, H, math, io16):
+    """gcngi_fwd_kernel is persistent (grid = min(tiles, 256), csrc/gcngi.hip) and the tests
+    above never give a workgroup more than one tile.  Here every workgroup runs its tile loop: the bench's own call
+    (34, 24, 4096, 102) = 98 304 rows = 3072 tiles of 32 rows (f16x3: 12 per workgroup) / 2048 of 48 (one-pass: 8 per
+    workgroup) -- the double-buffered g tile flips, the GCN waves prefetch X across tile boundaries (row_of(idx + 1)) --;
+    4097 windows put a ragged 24-row tile behind full ones; 1700 / 2500 x 5 rows give some workgroups two tiles and others
+    one (266 / 391 tiles in f16x3, 178 / 261 one-pass) with a ragged tail; S = 20 is the two-row-tile instance (NT = 2).
+    Bitwise against the two-launch path with and without a stash, 16-bit I/O, wgnn_fwd_last -- src/main.py:100-102 is the
+    call being served -- and the LAST 256 windows (the tail tiles) and the first 64 against the fp64 oracle."""
+    from oracle import windgnn_oracle as orc
+    res, (A, X, L, p) = _fused_vs_unfused(S, T, B, H, math, io16)
+    _assert_bitwise(res)
+    y_tol = F16_Y_TOL if math == "f16" else Y_TOL
+    pd = {k: v.double() for k, v in p.items()}
+    for sl in (slice(B - 256, B), slice(0, 64)):
+        Yo = orc.forward(A.cpu().double(), X[sl].cpu().double(), pd, want_cache=False)
+        Yo = Yo[0] if isinstance(Yo, tuple) else Yo
+        assert max_abs(res[2][3][sl], Yo.reshape(res[2][3][sl].shape)) <= y_tol, sl
 
 
 def test_wide_gru_mixed_mode_against_oracle_and_its_threshold():

@@ -13,8 +13,8 @@ tr = TrainStep(m)
 A = adjacency_34().to(dev)
 X, L = make_inputs(4096, 0, dev, io=io)
 tr.step(A, X, L)
-for fused in ("0", "2"):
-    os.environ["WGNN_FUSED_FWD"] = fused
+for fused in (0, 2):
+    _lib.set_option(_lib.OPT_FUSED_FWD, fused)     # (the environment variable is read once; round 5)
     for what in ("forward only (no stash)", "training step"):
         fn = (lambda: gcn_gru_forward_raw(A, X, tr.p_views, m.math, want_stash=False, prepared=tr._prepared)) \
             if what.startswith("forward") else (lambda: tr.step(A, X, L))

@@ -33,6 +33,13 @@ def step(mode):
     if mode == "seq":
         bw(2); bw(4)
     elif mode == "dg|tn":          # dg GEMM on the main stream next to the two TN GEMMs on the side stream, the GCN backward after both
+        # the committed library never read WGNN_EXP_PART2 (the split of part 2 lived in an experiment build that was
+        # not kept), so on the shipped tree this mode would run part 2 twice and time nonsense.  Refused unless such a build
+        # announces itself.
+        if os.environ.get("WGNN_LIB_SPLITS_PART2") != "1":
+            raise SystemExit('overlap_bwd.py: mode "dg|tn" needs the round-4 experiment build that splits backward part 2 '
+                             "(WGNN_EXP_PART2); the committed library does not, so its numbers in the docstring cannot be "
+                             "reproduced from this tree.  Modes seq / two run on the shipped library.")
         main = torch.cuda.current_stream()
         e1.record(main)
         side.wait_event(e1)

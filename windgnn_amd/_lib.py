@@ -19,6 +19,7 @@ ADJ_DENSE = 0
 ADJ_CSR = 1
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2   # wgnn_io: element type of X, Y and the labels
 STATUS_BYTES = 256          # WGNN_STATUS_BYTES: status block at the start of every workspace
+OPT_FUSED_FWD = 0           # WGNN_OPT_FUSED_FWD (wgnn_set_option): 0 never / 1 stash-less forwards / 2 every supported forward
 
 
 class Dims(C.Structure):
@@ -52,6 +53,8 @@ FINISH_ADAM_CONV = 32
 EXPORTS = {
     "wgnn_version": (C.c_int, []),
     "wgnn_strerror": (C.c_char_p, [C.c_int]),
+    "wgnn_set_option": (C.c_int, [C.c_int, C.c_int]),
+    "wgnn_get_option": (C.c_int, [C.c_int]),
     "wgnn_workspace_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "wgnn_stash_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "wgnn_fwd": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
@@ -113,7 +116,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.wgnn_version() < 121:
+    if lib.wgnn_version() < 122:
         raise RuntimeError("windgnn_amd: libwindgnn_hip.so is too old")
     _lib = lib
     return lib
@@ -123,6 +126,21 @@ def check(status: int, what: str) -> None:
     if status != 0:
         msg = load().wgnn_strerror(status).decode()
         raise RuntimeError("windgnn_amd: %s failed: %s (status %d)" % (what, msg, status))
+
+
+def set_option(key: int, value: int) -> int:
+    """wgnn_set_option: returns the previous value; raises on an unknown key / value."""
+    prev = load().wgnn_set_option(key, value)
+    if prev < 0:
+        check(prev, "wgnn_set_option(%d, %d)" % (key, value))
+    return prev
+
+
+def get_option(key: int) -> int:
+    v = load().wgnn_get_option(key)
+    if v < 0:
+        check(v, "wgnn_get_option(%d)" % key)
+    return v
 
 
 def profile_enable(on: bool) -> None:

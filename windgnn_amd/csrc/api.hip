@@ -1,8 +1,10 @@
 // extern "C" entry points of libwindgnn_hip.so (declared in include/windgnn.h).
 // Orchestrates the kernels of gcn.hip / gemm.hip / gru.hip / train_ops.hip on the caller's stream,
 // inside caller-owned workspace and stash buffers.  No allocation, no host synchronisation.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -225,16 +227,37 @@ void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float
   }
 }
 
-// WGNN_FUSED_FWD (environment, read per call): which forwards run the fused GCN + projection kernel (gcngi.hip).
-//   unset / "1"  forwards WITHOUT a stash (inference: wgnn_fwd(stash = NULL), wgnn_fwd_last) -- where it measured faster
+// Process-wide options (wgnn_set_option / wgnn_get_option).  None of them changes a result bit.
+//
+// WGNN_OPT_FUSED_FWD: which forwards run the fused GCN + projection kernel (gcngi.hip).
+//   1 (default)  forwards WITHOUT a stash (inference: wgnn_fwd(stash = NULL), wgnn_fwd_last) -- where it measured faster
 //                (B = 4096: f16x3 238 -> 215 us, f16 + bf16 I/O 149 -> 139 us; no g plane reaches HBM);
-//   "2"          every forward it supports, training too (there the stash copy of g makes it slower: 742 -> 770 us per step
-//                in f16x3, 514.5 -> 514.4 in f16: DESIGN.md section 5, round 4);
-//   "0"          never.  The results are bit-identical either way (tests/test_gpu_parity.py).
+//   2            every forward it supports, training too (there the stash copy of g makes it slower: 742 -> 770 us per step
+//                in f16x3, 514.5 -> 514.4 in f16: DESIGN.md, fused front end);
+//   0            never.  The results are bit-identical either way (tests/test_gpu_parity.py).
+// The initial value comes from the environment variable WGNN_FUSED_FWD, read ONCE (a getenv per call let the
+// path change mid-process and raced with putenv from other threads); afterwards only wgnn_set_option changes it.
+std::atomic<int> g_opt[WGNN_OPT_COUNT];
+std::once_flag g_opt_once;
+
+int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = getenv(name);
+  if (!e || !e[0]) return dflt;
+  char* end = nullptr;
+  const long v = strtol(e, &end, 10);
+  return (end == e || v < lo || v > hi) ? dflt : (int)v;
+}
+
+void init_options() {
+  std::call_once(g_opt_once, [] {
+    for (int k = 0; k < WGNN_OPT_COUNT; ++k) g_opt[k].store(0, std::memory_order_relaxed);
+    g_opt[WGNN_OPT_FUSED_FWD].store(env_int("WGNN_FUSED_FWD", 1, 0, 2), std::memory_order_relaxed);
+  });
+}
+
 int fused_fwd_mode() {
-  const char* e = getenv("WGNN_FUSED_FWD");
-  if (!e || !e[0]) return 1;
-  return e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1);
+  init_options();
+  return g_opt[WGNN_OPT_FUSED_FWD].load(std::memory_order_relaxed);
 }
 
 int check_dims(const wgnn_dims* d) {
@@ -268,6 +291,19 @@ int check_dims(const wgnn_dims* d) {
 extern "C" {
 
 int wgnn_version(void) { return WGNN_VERSION; }
+
+int wgnn_get_option(int key) {
+  if (key < 0 || key >= WGNN_OPT_COUNT) return WGNN_ERR_SHAPE;
+  init_options();
+  return g_opt[key].load(std::memory_order_relaxed);
+}
+
+int wgnn_set_option(int key, int value) {
+  if (key < 0 || key >= WGNN_OPT_COUNT) return WGNN_ERR_SHAPE;
+  if (key == WGNN_OPT_FUSED_FWD && (value < 0 || value > 2)) return WGNN_ERR_SHAPE;
+  init_options();
+  return g_opt[key].exchange(value, std::memory_order_relaxed);
+}
 
 const char* wgnn_strerror(int status) {
   switch (status) {

@@ -16,7 +16,12 @@ The loss a step returns is a 0-dim VIEW of the bucket's header (no clone launch 
 `.clone()` it before the next step -- a list of kept losses would all show the latest value.
 
 A rank whose shard is EMPTY (fewer windows than ranks) still issues every collective of the step: it contributes a zero
-bucket and runs the optimiser's launch on the summed gradient, so no rank is left waiting in an all-reduce."""
+bucket and runs the optimiser's launch on the summed gradient, so no rank is left waiting in an all-reduce.
+
+A step that RAISES (a refused launch, a failed collective) leaves the optimiser state undefined: `steps` counts completed
+steps only, but in the two-collective form the GRU tensors and their moments may already have been stepped when a later
+launch of the same step fails, and a retry would then apply the same bias-correction step number to them twice.  Do not
+retry a failed step on the same TrainStep: rebuild it from a checkpoint of the parameters (state_dict) instead."""
 from __future__ import annotations
 
 import torch
@@ -30,7 +35,8 @@ from .modules import GCN_GRU
 
 class TrainStep:
     def __init__(self, model: GCN_GRU, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group=None, check_every: int = 100, overlap_collectives: bool = False, direct_rccl=None):
+                 process_group=None, check_every: int = 100, overlap_collectives: bool = False, direct_rccl=None,
+                 rccl_loader=None):
         self.model = model
         self.params = list(model.hot_path_parameters())
         sizes = [p.numel() for p in self.params]
@@ -64,12 +70,13 @@ class TrainStep:
         # an explicitly passed group runs the collective path even with one rank (the all-reduces execute)
         self.collective = self.world > 1 or process_group is not None
         self.overlap_collectives = overlap_collectives
-        # direct_rccl: None = on for GPU buckets on the nccl backend unless WGNN_RCCL_DIRECT=0 (distributed.DirectRccl); the
-        # two-collective form overlaps through torch.distributed's own stream by design and never takes it
+        # direct_rccl: None = only if WGNN_RCCL_DIRECT=1 (opt-in: distributed.DirectRccl); the two-collective form overlaps
+        # through torch.distributed's own stream by design and never takes it
         self.exchange = None
         if self.collective:
             self.exchange = BucketExchange(self._gbuf, self.n_conv, process_group,
-                                           False if (overlap_collectives and direct_rccl is None) else direct_rccl)
+                                           False if (overlap_collectives and direct_rccl is None) else direct_rccl,
+                                           rccl_loader)
         self.check_every = check_every          # f16x3 / f16: read the library's range-status word every N steps
         self.device = dev
 
@@ -197,16 +204,36 @@ class TrainStep:
                                          prepared=pre)
             finish_step(d, self.p_views, self.g_views, 6, self._adam(), pre, self.device)              # :79 tail + :80
         self.steps += 1                         # only a step whose launches were all accepted counts
-        if self.check_every and self.model.math != _lib.MATH_F32 and self.steps % self.check_every == 0:
+        if self.check_every and self.steps % self.check_every == 0 and (
+                self.model.math != _lib.MATH_F32 or (self.exchange is not None and self.exchange.direct is not None)):
             self.check()
         return loss, Y
 
     def close(self):
-        """Release the step's own RCCL communicator, if it has one (before torch.distributed.destroy_process_group)."""
-        if self.exchange is not None and self.exchange.direct is not None:
-            self.exchange.direct.close()
-            self.exchange.direct = None
+        """Release the step's own RCCL communicator, if it has one (before torch.distributed.destroy_process_group).
+        Also runs from `with TrainStep(...) as tr:` and, as a last resort, from __del__."""
+        ex = getattr(self, "exchange", None)
+        if ex is not None and ex.direct is not None:
+            ex.direct.close()
+            ex.direct = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:           # interpreter shutdown: the library may be gone already
+            pass
 
     def check(self):
-        """Raise if a kernel of the fp16-plane modes reported a value outside fp16's range (one 4-byte read)."""
-        check_range_status(self.device)
+        """Raise if a kernel of the fp16-plane modes reported a value outside fp16's range (one 4-byte read), or if the
+        step's own RCCL communicator reported an asynchronous error (ncclCommGetAsyncError)."""
+        if self.exchange is not None and self.exchange.direct is not None:
+            self.exchange.direct.check()
+        if self.model.math != _lib.MATH_F32:
+            check_range_status(self.device)
