@@ -155,7 +155,7 @@ typedef struct wgnn_adam {
 int wgnn_version(void);
 const char* wgnn_strerror(int status);
 
-/* Process-wide options: which of two bit-identical kernel schedules runs.  No option changes a result bit; there is no
+/* Process-wide options: which of two bit-identical kernel schedules runs.  Options 0-3 do not change a result bit, option 4 only the summation order of some products; there is no
  * reference counterpart (the reference has no kernels to choose between).  wgnn_set_option returns the PREVIOUS value (>= 0)
  * or WGNN_ERR_SHAPE for an unknown key / value; it takes effect for calls issued after it returns and is atomic, but callers
  * that flip an option while other threads launch get either schedule for those launches.
@@ -163,7 +163,19 @@ const char* wgnn_strerror(int status);
  *                       projection kernel (csrc/gcngi.hip).  Initial value: environment variable WGNN_FUSED_FWD, read once at
  *                       the first call that needs it (never again). */
 #define WGNN_OPT_FUSED_FWD 0
-#define WGNN_OPT_COUNT 1
+/* Measurement aids (same results, another schedule; defaults 0 / 0 / 1): roles of the fused kernel's waves assigned per SIMD
+ * instead of per wave index (0 / 1); s_setprio level of its projection waves (0..3); backward part 2 (dg GEMM -> GCN backward)
+ * as 1 / 2 / 4 / 8 producer -> consumer pairs over row chunks (taken only where every chunk still fills the chip; must not
+ * change between a WGNN_BWD_DEFER part 2 and its wgnn_finish). */
+#define WGNN_OPT_GG_ROLE_SPLIT 1
+#define WGNN_OPT_GG_GEMM_PRIO 2
+#define WGNN_OPT_BWD2_CHUNKS 3
+#define WGNN_BWD2_MAX_CHUNKS 8
+/* 1 (default): NT plane products with >= 1024 rows, >= 2048 columns and a contraction >= 1024 long (BASELINE configs[4]) run
+ * the 256 x 256-tile kernel of csrc/pgemm_big.hip; 0: the 192 x 448-tile kernel shaped for the 34-station widths.  The two sum
+ * each dot product in a different order (results differ by fp32 rounding, inside every stated tolerance). */
+#define WGNN_OPT_BIG_GEMM 4
+#define WGNN_OPT_COUNT 5
 int wgnn_set_option(int key, int value);
 int wgnn_get_option(int key);
 

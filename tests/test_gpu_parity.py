@@ -1553,3 +1553,86 @@ def test_4096_station_config_full_size_properties_B128_T24(math):
     check_range_status(dev)
     del G, G4, params, model
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("math", ["f16x3", "f16x3g", "f16"])
+def test_backward_part2_in_row_chunks_equals_one_launch(math):
+    """WGNN_OPT_BWD2_CHUNKS (a schedule option): dg GEMM -> GCN backward as 2 / 4 / 8 producer -> consumer
+    pairs over row chunks.  The GRU gradients do not depend on it at all; the conv gradients are the same per-tile products
+    summed over per-workgroup partial rows in another grouping: 2e-6 of max against the single launch pair, and still inside
+    the mode's tolerance against the fp64 oracle.  Chunks that would not fill the chip are refused silently (1536 windows x 24
+    = 36 864 rows: 8 chunks of 4608 rows = 24 GEMM tiles are taken; 1537 windows: no chunk count divides, one launch)."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd import _lib
+    dev = _dev()
+    S, T, H = 34, 24, 102
+    p = orc.init_params(S, 13, H, seed=9)
+    g = torch.Generator().manual_seed(55)
+    A = torch.rand(S, S, generator=g) / S + 0.01
+    for B in (1536, 1537):
+        X = torch.rand(B, T, S, 13, generator=g)
+        L = torch.rand(B, T, H, generator=g)
+        res = {}
+        try:
+            for ch in (1, 2, 4, 8):
+                _lib.set_option(_lib.OPT_BWD2_CHUNKS, ch)
+                res[ch] = _run_step(_model_from(p, S, H, math), A.to(dev), X.to(dev), L.to(dev))
+        finally:
+            _lib.set_option(_lib.OPT_BWD2_CHUNKS, 1)
+        for ch in (2, 4, 8):
+            assert torch.equal(res[1][0], res[ch][0]) and res[1][1] == res[ch][1]
+            for k in PARAM_KEYS:
+                if k.startswith("gru") or B == 1537:
+                    assert torch.equal(res[1][2][k], res[ch][2][k]), (B, ch, k)
+                else:
+                    assert rel_to_max(res[ch][2][k], res[1][2][k]) <= 2e-6, (B, ch, k)
+        if B == 1536:
+            assert any(not torch.equal(res[1][2][k], res[8][2][k]) for k in PARAM_KEYS[:4])      # the chunked schedule really ran
+            Yo, loss_o, go = orc.train_step(A.double(), X.double(), L.double(), {k: v.double() for k, v in p.items()})
+            tol = F16_G_TOL if math == "f16" else G_TOL
+            for k in PARAM_KEYS:
+                assert rel_to_max(res[8][2][k], go[k]) <= tol, k
+
+
+@pytest.mark.parametrize("math,B", [("f16x3", 48), ("f16x3g", 128)])
+def test_large_plane_gemm_instance_against_oracle(math, B):
+    """csrc/pgemm_big.hip (256 x 256 tiles of 32x32x16 MFMAs) takes the NT plane products with >= 1024 rows,
+    >= 2048 columns and a contraction >= 1024 long -- BASELINE configs[4]'s projections.  The full-size property test of that
+    configuration cannot see a GEMM that is linear but wrong, so here is the smallest model whose GI = g W_ih^T (1152 x 2100 x
+    2600) and dg = dGI W_ih (1152 x 2600 x 2100) both take it, with ragged tiles on every side (1152 = 4.5 row tiles, 2100 = 8.2
+    / 2600 = 10.2 column tiles), against the fp64 oracle at SURVEY 8(c)'s bar -- and against the 192 x 448-tile kernel
+    (WGNN_OPT_BIG_GEMM = 0: the same products summed in another order).  f16x3g with 128 windows = 3072 rows is past the wide
+    path's mixed-mode threshold: dg then runs the kernel's two-pass instance (single-plane A operand)."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd import _lib
+    from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
+    dev = _dev()
+    S, T, H = 200, 24, 700
+    csr = CsrAdjacency(*build_knn_adjacency(synthetic_station_coords(S, seed=3), 8))
+    g = torch.Generator().manual_seed(808)
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    p = orc.init_params(S, 13, H, seed=4)
+    p["conv1.weight"] *= 0.3                                     # keeps g (a sum over 8 neighbours of randn-weighted features) O(1)
+    p["conv2.weight"] *= 0.3
+    Yo, loss_o, go = orc.train_step(csr.dense().double(), X.double(), L.double(), {k: v.double() for k, v in p.items()})
+    res = {}
+    try:
+        for big in (1, 0):
+            _lib.set_option(_lib.OPT_BIG_GEMM, big)
+            _lib.profile_enable(True)
+            res[big] = _run_step(_model_from(p, S, H, math), csr.to(dev), X.to(dev), L.to(dev))
+            torch.cuda.synchronize()
+            names = {r["name"] for r in _lib.profile_read()}
+            _lib.profile_enable(False)
+            assert any(n.startswith("pgemm_nt256") for n in names) == bool(big), names     # the kernel under test really ran
+    finally:
+        _lib.set_option(_lib.OPT_BIG_GEMM, 1)
+        _lib.profile_enable(False)
+    for big in (1, 0):
+        out, loss, grads = res[big]
+        assert max_abs(out.reshape(Yo.shape), Yo) <= Y_TOL, big
+        assert abs(loss - float(loss_o)) <= 1e-5 * max(1.0, float(loss_o))
+        worst = {k: rel_to_max(grads[k], go[k]) for k in PARAM_KEYS}
+        assert max(worst.values()) <= G_TOL, (big, worst)
+    assert max_abs(res[1][0], res[0][0]) <= 2e-5

@@ -169,6 +169,7 @@ Layout make_layout(const wgnn_dims* d) {
   {
     size_t a = gcn32_bwd_partial_floats((int)L.BT), b = gcnx2_bwd_partial_floats((int)L.BT);
     if (L.gen_gcn) a = gcn_csr_bwd_partial_floats();
+    b *= WGNN_BWD2_MAX_CHUNKS;                                         // (chunked part 2: one set of partial rows per chunk)
     L.ws_gcnpart = o; o += al(a > b ? a : b);
   }
   L.ws_du = o; o += al(L.gen_gcn ? L.BT * L.I : 0);
@@ -184,6 +185,8 @@ Layout make_layout(const wgnn_dims* d) {
   L.bwd_floats = o;
   return L;
 }
+
+int bwd2_chunks(const Layout& L);
 
 // The reduction half of a finish launch: which & 4 -> the split-K partials of the two GRU weight-gradient products,
 // which & 2 -> the per-workgroup partial rows of the GCN backward; gradients go to `g`.
@@ -222,8 +225,10 @@ void fill_reduce(const Layout& L, const wgnn_dims* d, const wgnn_grads* g, float
   }
   if (which & 2) {
     a.conv_partial = ws + L.ws_gcnpart;
+    const int ch = bwd2_chunks(L);      // (the option must not change between a deferred part 2 and its wgnn_finish)
     a.conv_rows = L.gen_gcn ? gcn_csr_bwd_rows()
-                            : (L.x3 ? gcnx_bwd_grid((int)L.BT, d->S, d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G) : gcn32_bwd_grid((int)L.BT, d->S));
+                            : (L.x3 ? ch * gcnx_bwd_grid((int)(L.BT / ch), d->S, d->math == WGNN_MATH_F16X3 || d->math == WGNN_MATH_F16X3G)
+                                    : gcn32_bwd_grid((int)L.BT, d->S));
   }
 }
 
@@ -252,7 +257,24 @@ void init_options() {
   std::call_once(g_opt_once, [] {
     for (int k = 0; k < WGNN_OPT_COUNT; ++k) g_opt[k].store(0, std::memory_order_relaxed);
     g_opt[WGNN_OPT_FUSED_FWD].store(env_int("WGNN_FUSED_FWD", 1, 0, 2), std::memory_order_relaxed);
+    g_opt[WGNN_OPT_BWD2_CHUNKS].store(1, std::memory_order_relaxed);
+    g_opt[WGNN_OPT_BIG_GEMM].store(1, std::memory_order_relaxed);
   });
+}
+
+int opt(int key) {
+  init_options();
+  return g_opt[key].load(std::memory_order_relaxed);
+}
+
+// WGNN_OPT_BWD2_CHUNKS: backward part 2 (dg GEMM -> GCN backward) as C producer -> consumer pairs over C row chunks, so that a
+// chunk of dg is read back while it is still cache-resident.  Only the dense fp16-plane path, only when
+// every chunk still fills the chip: whole 192-row GEMM tiles, >= 12 GCN tiles per workgroup.  Else 1.
+int bwd2_chunks(const Layout& L) {
+  const int c = opt(WGNN_OPT_BWD2_CHUNKS);
+  if (c <= 1 || !L.x3 || L.gen_gcn || L.gen_gru) return 1;
+  if (L.BT % (size_t)c != 0 || (L.BT / c) % 192 != 0 || L.BT / c < 3072) return 1;
+  return c;
 }
 
 int fused_fwd_mode() {
@@ -288,6 +310,8 @@ int check_dims(const wgnn_dims* d) {
 
 }  // namespace
 
+bool opt_big_gemm() { return opt(WGNN_OPT_BIG_GEMM) != 0; }
+
 extern "C" {
 
 int wgnn_version(void) { return WGNN_VERSION; }
@@ -301,6 +325,10 @@ int wgnn_get_option(int key) {
 int wgnn_set_option(int key, int value) {
   if (key < 0 || key >= WGNN_OPT_COUNT) return WGNN_ERR_SHAPE;
   if (key == WGNN_OPT_FUSED_FWD && (value < 0 || value > 2)) return WGNN_ERR_SHAPE;
+  if ((key == WGNN_OPT_GG_ROLE_SPLIT && (value < 0 || value > 1)) || (key == WGNN_OPT_GG_GEMM_PRIO && (value < 0 || value > 3)))
+    return WGNN_ERR_SHAPE;
+  if (key == WGNN_OPT_BIG_GEMM && (value < 0 || value > 1)) return WGNN_ERR_SHAPE;
+  if (key == WGNN_OPT_BWD2_CHUNKS && value != 1 && value != 2 && value != 4 && value != WGNN_BWD2_MAX_CHUNKS) return WGNN_ERR_SHAPE;
   init_options();
   return g_opt[key].exchange(value, std::memory_order_relaxed);
 }
@@ -376,7 +404,7 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
       const int planes = sf ? ((full && !L.dgi1) ? 2 : 1) : 0;     // what the backward reads of g: hi (mask, one-pass dW_ih), + lo (strict)
       rc = launch_gcngi_fwd((int)L.BT, d->S, A, X, d->io, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias,
                             sf ? (void*)g : nullptr, (int)L.Ip, planes, img_f, L.np_g3, GI, (int)L.Gp, (int)L.G3, full, status,
-                            ws + L.ws_xtail_f, st);
+                            ws + L.ws_xtail_f, st, opt(WGNN_OPT_GG_ROLE_SPLIT), opt(WGNN_OPT_GG_GEMM_PRIO));
       if (rc != WGNN_OK) return rc;
       if (last)
         return launch_grux_fwd(d->B, d->T, d->H, GI, (int)L.Gp, p->w_hh, p->b_hh, last, nullptr, nullptr, full, status,
@@ -682,6 +710,25 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     if (!kept) {
       rc = launch_split_weight2(p->w_ih, (int)L.G3, (int)L.I, 1, nullptr, 0, img_b, L.np_i, (int)L.Gp, status, st);
       if (rc != WGNN_OK) return rc;
+    }
+    const int chunks = bwd2_chunks(L);
+    if (chunks > 1) {     // producer -> consumer pairs over row chunks (WGNN_OPT_BWD2_CHUNKS); same products, same partial sums per tile
+      const size_t rows = L.BT / chunks;
+      const size_t es = d->io ? 2 : 4, dgs = L.dg16 ? 2 : 4;
+      const int prow = gcnx_bwd_grid((int)rows, d->S, full);
+      for (int c = 0; c < chunks; ++c) {
+        const size_t r0 = (size_t)c * rows;
+        rc = launch_pgemm_nt(dGIh + r0 * L.Gp, dGIlo ? dGIlo + r0 * L.Gp : nullptr, (int)L.Gp, (int)rows, (int)L.Gp, img_b, L.np_i,
+                             (float*)((char*)dg + r0 * L.Id * dgs), (int)L.Id, (int)L.I, nullptr, full, nullptr, st, L.dg16);
+        if (rc != WGNN_OK) return rc;
+        rc = launch_gcnx2_bwd((int)rows, d->S, A, (const char*)Xv + r0 * L.I * es, d->io, p->conv1_weight, p->conv1_bias,
+                              p->conv2_weight, gh + r0 * L.Ip, (int)L.Ip, (const char*)dg + r0 * L.Id * dgs, (int)L.Id, L.dg16,
+                              scales, /*scale_in=*/0, ws + L.ws_gcnpart + (size_t)c * prow * gcnx2_bwd_partial_floats((int)rows) / 256,
+                              full, ws + L.ws_xtail_b, st);
+        if (rc != WGNN_OK) return rc;
+      }
+      if (defer) return WGNN_OK;
+      return reduce_now(2);
     }
     rc = launch_pgemm_nt(dGIh, L.gen_gru ? (L.gen2p ? nullptr : dGIh + PG) : dGIlo, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.Id,
                          (int)L.I, nullptr, full, nullptr, st, L.dg16);

@@ -160,7 +160,24 @@ int launch_gcnx2_bwd(int ntiles, int S, const float* A, const void* X, int io, c
 bool gcngi_supported(int S, int H, bool x3);
 int launch_gcngi_fwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, int stash_planes, const void* Bplanes,
-                     int Np, void* GI, int ldgi, int N, bool x3, unsigned* status, void* xtail_scratch, hipStream_t st);
+                     int Np, void* GI, int ldgi, int N, bool x3, unsigned* status, void* xtail_scratch, hipStream_t st,
+                     int role_split = 0, int gemm_prio = 0);
+// large-shape NT plane GEMM (pgemm_big.hip); opt_big_gemm(): WGNN_OPT_BIG_GEMM (api.hip), 1 unless switched off for an A/B
+bool pgemm_nt256_wanted(int M, int N, int Kp);
+int launch_pgemm_nt256(const void* Ahi, const void* Alo, int lda, int M, int k0, int klen, const void* Bplanes, int Np,
+                       size_t bplane, float* C, int ldc, int N, bool accumulate, hipStream_t st);
+bool opt_big_gemm();
+// ---- The image of a B operand (weights: W_ih | b_ih, W_ih^T, W_hh | b_hh), written by split_weight2_kernel / finish.hip and
+// staged by the NT plane GEMMs and the fused front end: one fp16 plane of B[Np][Kp] is STAGE-major (a 32-deep K step of all
+// Np rows is contiguous) and, since round 5, FRAGMENT-major inside a stage: the 16 rows x 32 k of one MFMA B fragment are 1 KB
+// laid out [k chunk c = (k >> 3) & 3][row r = n & 15][8 halfs], i.e. lane l = 16 c + r of a 16x16x32 B fragment owns bytes
+// [16 l, 16 l + 16).  A fragment is then ONE linear 1 KB load (global_load_dwordx4, or LDS-DMA followed by a linear
+// ds_read_b128): the row-major form of rounds 1-4 ([n][32 k], 64-byte rows) made the fused kernel's register loads lane-
+// transposed (consecutive lanes 64 bytes apart), which the CU's address path serves at 30 B/clk against 51-54 for the linear
+// form (tools/l2_stream.hip, profiles/r5_l2_stream.txt).
+__host__ __device__ __forceinline__ size_t bimg_off(int n, int k, int Np) {
+  return ((size_t)(k >> 5) * (size_t)(Np >> 4) + (size_t)(n >> 4)) * 512 + (size_t)(((k >> 3) & 3) * 128 + (n & 15) * 8 + (k & 7));
+}
 // plane GEMMs (pgemm.hip)
 int launch_split_weight2(const float* W, int R, int C, int transpose, const float* bias, int bias_col, void* planes,
                          int Rp, int Cp, unsigned* status, hipStream_t st);

@@ -39,11 +39,11 @@ __device__ __forceinline__ void emit(const FinishArgs& a, int t, int64_t idx, in
     float ws = w;
     asm volatile("" : "+v"(ws));          // split the stored fp32 value (no fp16-output fma contraction: see seg_tn)
     const _Float16 h = (_Float16)ws, l = (_Float16)(ws - (float)h);
-    const size_t f = (size_t)(col >> 5) * a.np_g3 * 32 + (size_t)row * 32 + (col & 31);
+    const size_t f = bimg_off(row, col, a.np_g3);
     a.pf_hi[f] = h;
     a.pf_lo[f] = l;
     if (t == T_WIH) {
-      const size_t b = (size_t)(row >> 5) * a.np_i * 32 + (size_t)col * 32 + (row & 31);
+      const size_t b = bimg_off(col, row, a.np_i);
       a.pb_hi[b] = h;
       a.pb_lo[b] = l;
     }
@@ -119,15 +119,15 @@ __device__ __forceinline__ void seg_tn(const FinishArgs& a, const FinSeg& s, int
       pk[r] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
     }
     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-    {  // W_ih^T image: (row, col) at [(row >> 5)][col][row & 31]
-      const size_t b = (size_t)(m0 >> 5) * a.np_i * 32 + (size_t)n * 32 + (m0 & 31);
+    {  // W_ih^T image: B row = column n of W_ih, k = W_ih row m0 .. m0 + 3 (4 consecutive halfs of one 16-byte fragment piece)
+      const size_t b = bimg_off(n, m0, a.np_i);
       us4 hh, ll;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { hh[r] = (unsigned short)(pk[r] & 0xffffu); ll[r] = (unsigned short)(pk[r] >> 16); }
       *(us4*)(a.pb_hi + b) = hh;
       *(us4*)(a.pb_lo + b) = ll;
     }
-    {  // forward image: (row, col) at [(col >> 5)][row][col & 31]; quad transpose: lane L of the quad ends with row m0 + L
+    {  // forward image: B row = W_ih row, k = 4 consecutive columns (bimg_off); quad transpose: lane L of the quad ends with row m0 + L
       const int L = lane & 3;
       const bool odd = L & 1, upper = L & 2;
       auto xch = [](unsigned x, auto ctrl) {
@@ -142,7 +142,7 @@ __device__ __forceinline__ void seg_tn(const FinishArgs& a, const FinSeg& s, int
       const unsigned s0 = xch(upper ? b0 : b2, X2{}), s1 = xch(upper ? b1 : b3, X2{});
       const unsigned c0 = upper ? s0 : b0, c1 = upper ? s1 : b1, c2 = upper ? b2 : s0, c3 = upper ? b3 : s1;
       const int row = m0 + L, col = n - L;                             // this lane's row, the quad's first column
-      const size_t f = (size_t)(col >> 5) * a.np_g3 * 32 + (size_t)row * 32 + (col & 31);
+      const size_t f = bimg_off(row, col, a.np_g3);
       us4 hh = {(unsigned short)(c0 & 0xffffu), (unsigned short)(c1 & 0xffffu), (unsigned short)(c2 & 0xffffu), (unsigned short)(c3 & 0xffffu)};
       us4 ll = {(unsigned short)(c0 >> 16), (unsigned short)(c1 >> 16), (unsigned short)(c2 >> 16), (unsigned short)(c3 >> 16)};
       *(us4*)(a.pf_hi + f) = hh;

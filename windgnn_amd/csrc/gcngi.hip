@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
     int ntiles, int S, const float* __restrict__ A, const void* __restrict__ X, const void* __restrict__ xtail, int io,
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
     const float* __restrict__ b2, _Float16* __restrict__ ghi, _Float16* __restrict__ glo, int ldp, int stash_planes,
-    const _Float16* __restrict__ Bpl, size_t bplane, int Np, void* __restrict__ GIv, int ldgi, int N, unsigned* status) {
+    const _Float16* __restrict__ Bpl, size_t bplane, int Np, void* __restrict__ GIv, int ldgi, int N, unsigned* status,
+    int role_split, int gemm_prio) {
   constexpr int KS = (NT + 1) / 2;
   constexpr int SP = 16 * NT;
   constexpr int NP = (SP * F13 / 2 + 63) / 64;
@@ -44,12 +45,26 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
   constexpr int PL = X3 ? 2 : 1;
   constexpr int RT = R / 16;
   static_assert(R % 16 == 0, "the projection works on 16-row MFMA tiles");
+  static_assert((NG + NM) % 4 == 0 && (4 * NG) % (NG + NM) == 0, "role_split maps roles to whole SIMD slots");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   h8* const sCA = (h8*)smem;                                              // [frag][hi|lo][lane]
   float* const sx = (float*)(smem + (size_t)2 * NF * 64 * 16);            // per GCN wave: [SP][XS] fp32
   char* const gt = smem + (size_t)2 * NF * 64 * 16 + (size_t)NG * SP * XS * 4;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Which waves play which role.  Default: waves 0..NG-1 GCN, the rest GEMM -- with the hardware's cyclic wave -> SIMD
+  // assignment every SIMD then hosts waves of both roles.  role_split (WGNN_OPT_GG_ROLE_SPLIT, an experiment: VERDICT r4
+  // next 2b) assigns roles by wave % 4 instead, i.e. per SIMD: NG : NM = 1 : 1 -> SIMD slots {0,1} GCN, {2,3} GEMM;
+  // 3 : 1 -> slot 3 GEMM.  gidx / q: the wave's index inside its role.  The results do not depend on it.
+  bool is_gcn = wave < NG;
+  int gidx = wave, q = wave - NG;
+  if (role_split) {
+    constexpr int GS = 4 * NG / (NG + NM);                                // SIMD slots that run GCN waves
+    const int slot = wave & 3, round = wave >> 2;
+    is_gcn = slot < GS;
+    gidx = round * GS + slot;
+    q = round * (4 - GS) + (slot - GS);
+  }
   const int I = S * F13;
   const int pitch = 2 * ldp + GG_PAD;                                     // bytes per g row in LDS
   const int plane_b = R * pitch, buf_b = PL * plane_b;
@@ -58,8 +73,8 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
   const int nit = (int)blockIdx.x < ntile_r ? (ntile_r - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
 
   // ---- one-time set-up: A fragments, zeroed staging, the constant tail of every g row (1.0 at column I, zeros behind)
-  if (wave < NG) {
-    float* xb0 = sx + wave * SP * XS;
+  if (is_gcn) {
+    float* xb0 = sx + gidx * SP * XS;
     for (int i = lane; i < SP * XS; i += 64) xb0[i] = 0.f;                 // pads (f >= 13, s >= S) stay zero forever
   }
   if (wave == 0) {
@@ -84,10 +99,10 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
   __syncthreads();
   if (nit == 0) return;
 
-  if (wave < NG) {
-    // =============================== GCN waves: rows wave, wave + NG, ... of every tile ===============================
+  if (is_gcn) {
+    // =============================== GCN waves: rows gidx, gidx + NG, ... of every tile ===============================
     float chk = 0.f;                                     // range check: see gcnx_fwd_kernel
-    float* xb = sx + wave * SP * XS;
+    float* xb = sx + gidx * SP * XS;
     constexpr bool HALF = (NT & 1) != 0;
     h4v ahh[HALF ? NT : 1], ahl[HALF ? NT : 1];
     if constexpr (HALF) {
@@ -143,13 +158,13 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bias1 = {bb1[0], bb1[1], bb1[2], bb1[3]}, bias2 = {bb2[0], bb2[1], bb2[2], bb2[3]};
     constexpr int RW = (R + NG - 1) / NG;                                  // rows per wave and tile (the last may be off)
-    const int nrw = (wave + NG * (RW - 1) < R) ? RW : RW - 1;              // wave-uniform
+    const int nrw = (gidx + NG * (RW - 1) < R) ? RW : RW - 1;              // wave-uniform
     const int total = nit * nrw;
     // idx-th row of this wave -> global row (tile of X), clamped into the tensor (rows past it are recomputed copies of
     // the last row: their g rows are never stored and the projection's rows past the tensor are never written)
     auto row_of = [&](int idx, int& tp, int& r) {
       tp = idx / nrw;
-      r = wave + NG * (idx % nrw);
+      r = gidx + NG * (idx % nrw);
       return ((int)blockIdx.x + tp * (int)gridDim.x) * R + r;
     };
     f32x2 xr[NP];
@@ -260,7 +275,11 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
 
   // =============================== GEMM waves: a slice of the 3H columns, all R rows ===============================
   {
-    const int q = wave - NG;
+    // (experiment, WGNN_OPT_GG_GEMM_PRIO: the GEMM waves' instructions -- their B loads above all -- win issue arbitration
+    // against the GCN waves of the same SIMD; s_setprio takes an immediate)
+    if (gemm_prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (gemm_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (gemm_prio == 3) __builtin_amdgcn_s_setprio(3);
     const int ntn = (N + 15) / 16;                                          // 16-column tiles of GI
     const int base = ntn / NM, extra = ntn % NM;
     const int nct = base + (q < extra ? 1 : 0);                             // wave-uniform
@@ -268,11 +287,13 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
     const int nk = ldp / 32;
     const int r16 = lane & 15, c4 = lane >> 4;
     // B fragment (column tile j, K step kt, plane pl) = 1 KB contiguous at Bpl + pl * bplane + (kt * Np + 16 (ct0 + j)) * 32
-    // halfs: a per-lane byte offset (fixed) on top of a scalar base that advances with kt; j rides in the immediate offset
+    // halfs, FRAGMENT-major since round 5 (common.h, bimg_off): lane l loads bytes [16 l, 16 l + 16) of it -- a linear 1 KB
+    // wave-load (the row-major image's load had consecutive lanes 64 bytes apart: 30 B/clk/CU instead of 51-54, tools/l2_stream.hip);
+    // a per-lane byte offset (fixed) on top of a scalar base that advances with kt; j rides in the immediate offset
     const size_t kstride_b = (size_t)Np * 64;                               // bytes per K step
     auto consume = [&](auto ctc, const char* buf, int m0, int ctb) {
       constexpr int CT = decltype(ctc)::value;
-      const unsigned boff = (unsigned)((((16 * ctb + r16) * 32) + 8 * c4) * 2);   // this lane's bytes inside a stage
+      const unsigned boff = (unsigned)(ctb * 1024 + lane * 16);   // this lane's bytes inside a stage: fragments are 1 KB, linear (bimg_off)
       f32x4 acc[RT][CT];
 #pragma unroll
       for (int i = 0; i < RT; ++i)
@@ -435,7 +456,8 @@ bool gcngi_supported(int S, int H, bool x3) {
 // [Kp / 32][Np][32] halfs, hi then lo (launch_split_weight2 / wgnn_prepare_weights), column I = b_ih.
 int launch_gcngi_fwd(int ntiles, int S, const float* A, const void* X, int io, const float* W1, const float* b1,
                      const float* W2, const float* b2, void* g_planes, int ldg, int stash_planes, const void* Bplanes,
-                     int Np, void* GI, int ldgi, int N, bool x3, unsigned* status, void* xtail_scratch, hipStream_t st) {
+                     int Np, void* GI, int ldgi, int N, bool x3, unsigned* status, void* xtail_scratch, hipStream_t st,
+                     int role_split, int gemm_prio) {
   const int NTs = (S + 15) / 16;
   const size_t I = (size_t)S * 13, es = io ? 2 : 4;
   const void* xt = nullptr;
@@ -465,7 +487,8 @@ int launch_gcngi_fwd(int ntiles, int S, const float* A, const void* X, int io, c
     PROF_LAUNCH(NAME, fl, by, st,                                                                                      \
                 hipLaunchKernelGGL((gcngi_fwd_kernel<NT, X3V, IOV, NGV, NMV, RV>), dim3(grid),                         \
                                    dim3(64 * (NGV + NMV)), smem, st, ntiles, S, A, X, xt, io, W1, b1, W2, b2, ghi,     \
-                                   glo, ldg, stash_planes, (const _Float16*)Bplanes, bplane, Np, GI, ldgi, N, status)); \
+                                   glo, ldg, stash_planes, (const _Float16*)Bplanes, bplane, Np, GI, ldgi, N, status,  \
+                                   role_split, gemm_prio));                                                            \
   } while (0)
 #define GG_CASE(NT)                                                                      \
   if (x3 && !io) GG_GO(NT, true, false, 8, 8, 32, "gcngi_fwd_kernel<" #NT ">");          \

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
     const int q = wave + NT_WAVES * it;
     onB[it] = q < PL * BP;                                          // wave-uniform
     const int plane = onB[it] ? q / BP : 0, blk = onB[it] ? q % BP : 0;
-    srcB[it] = Bpl + (size_t)plane * bplane + (size_t)(n0 + 16 * blk + prow) * 32 + chunk;
+    srcB[it] = Bpl + (size_t)plane * bplane + (size_t)(n0 / 16 + blk) * 512 + lane * 8;   // one fragment: 1 KB, linear (bimg_off)
     dstB[it] = plane * B_PL + blk * 1024;
   }
   const int nk = Kp / 32;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(64 * NT_WAVES) pgemm_nt_kernel(const _Float16*
                                          (lds_void*)(ringB + slot * B_SLOT + dstB[it]), 16, 0, 0);
   };
   const int a_off0 = sw16_off(32 * wm + r16, c4), a_off1 = a_off0 + 16 * 64;
-  const int b_off = sw16_off(BNW * wn + r16, c4);
+  const int b_off = T * wn * 1024 + lane * 16;      // B pieces are fragment-major: lane l owns bytes [16 l, 16 l + 16) of each
   auto compute = [&](const char* curA, const char* curB) {
     const char* Ah = curA;
     const char* Al = curA + A_PL;
@@ -513,14 +513,16 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
 }
 
 // Planes of O[Rp][Cp] (O[r][c] = transpose ? W[c][r] : W[r][c]; optional extra column `bias_col`
-// holding bias[r]; zero elsewhere) from fp32 W[R][C], STAGE-MAJOR: (r,c) at [(c/32)][r][c%32].
+// holding bias[r]; zero elsewhere) from fp32 W[R][C], in the B-image layout bimg_off(r, c, Rp) (common.h): stage-major, and
+// fragment-major inside a stage.  Thread i writes element i of the image (coalesced stores).
 __global__ void split_weight2_kernel(const float* __restrict__ W, int R, int C, int transpose,
                                      const float* __restrict__ bias, int bias_col, _Float16* hi, _Float16* lo,
                                      int Rp, int Cp, unsigned* status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Rp * Cp) return;
-  const int kt = i / (Rp * 32), rem = i % (Rp * 32);
-  const int r = rem / 32, c = 32 * kt + rem % 32;
+  const int tile = i >> 9, within = i & 511;                      // 1 KB fragments: [K step][16-row tile][k chunk][row][8]
+  const int kt = tile / (Rp >> 4), nt = tile % (Rp >> 4);
+  const int r = 16 * nt + ((within >> 3) & 15), c = 32 * kt + 8 * (within >> 7) + (within & 7);
   float v = 0.f;
   if (transpose) { if (c < R && r < C) v = W[(size_t)c * C + r]; }
   else {
@@ -659,6 +661,18 @@ static int launch_nt_t(const void* Ahi, const void* Alo, int lda, int M, int Kp,
 // C[M][N] = s_out * A B^T.  A planes [M][lda] (Kp <= lda), B stage-major planes with Np = pgemm_nt_np(N) rows.
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
                     int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st, bool out16) {
+  // many rows AND many columns AND a long contraction (configs[4]'s projections): the 256 x 256 / 32x32x16 kernel of
+  // pgemm_big.hip, one launch per K chunk (chunk sums added onto C, as below)
+  if (x3 && !out16 && !kpart && !s_out && pgemm_nt256_wanted(M, N, Kp) && Kp % 32 == 0 && lda % 8 == 0 &&
+      Np >= cdiv_i(N, 256) * 256 && opt_big_gemm()) {
+    const int nchunks = nt_chunks(Kp), kc_len = nchunks > 1 ? NT_KC : Kp;
+    for (int c = 0; c < nchunks; ++c) {
+      const int k0 = c * kc_len, klen = Kp - k0 < kc_len ? Kp - k0 : kc_len;
+      const int rc = launch_pgemm_nt256(Ahi, Alo, lda, M, k0, klen, Bplanes, Np, (size_t)Np * Kp, C, ldc, N, c > 0, st);
+      if (rc != WGNN_OK) return rc;
+    }
+    return WGNN_OK;
+  }
   int nsl, T;
   nt_shape(M, N, Kp, kpart != nullptr, nsl, T);
   if (Kp % 32 != 0 || lda % 8 != 0 || Np < nsl * 32 * T) return WGNN_ERR_SHAPE;
