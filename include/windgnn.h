@@ -172,8 +172,9 @@ const char* wgnn_strerror(int status);
 #define WGNN_OPT_BWD2_CHUNKS 3
 #define WGNN_BWD2_MAX_CHUNKS 8
 /* 1 (default): NT plane products with >= 1024 rows, >= 2048 columns and a contraction >= 1024 long (BASELINE configs[4]) run
- * the 256 x 256-tile kernel of csrc/pgemm_big.hip; 0: the 192 x 448-tile kernel shaped for the 34-station widths.  The two sum
- * each dot product in a different order (results differ by fp32 rounding, inside every stated tolerance). */
+ * the 256 x 256-tile kernel of csrc/pgemm_big.hip with their activation operand rewritten as an image first; 2: the same
+ * kernel staging that operand row-major (a measurement aid); 0: the 192 x 448-tile kernel shaped for the 34-station widths.
+ * 0 and 1 / 2 sum each dot product in a different order (results differ by fp32 rounding, inside every stated tolerance). */
 #define WGNN_OPT_BIG_GEMM 4
 #define WGNN_OPT_COUNT 5
 int wgnn_set_option(int key, int value);
@@ -267,14 +268,28 @@ size_t wgnn_prepared_bytes(const wgnn_dims* d);
 int wgnn_prepare_weights(const wgnn_dims* d, const wgnn_params* p, void* workspace, size_t workspace_bytes,
                          void* stream);
 
-/* One GraphConvLayer: out[n,S,F] = relu(A X[n] W + b) for n = 0..ntiles-1 (ntiles = prod of the
- * leading dims of attr_matrix).  Backward: dW, db (overwritten) and, if dX != NULL, dX. */
-size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F);
-int wgnn_gcn_layer_fwd(int32_t ntiles, int32_t S, int32_t F, const float* A, const float* X,
+/* One GraphConvLayer(F, F_out) (src/step5_gcn_layer_model.py:5-23: weight [F, F_out], bias [F_out]):
+ * out[n,S,F_out] = relu(A X[n] W + b) for n = 0..ntiles-1 (ntiles = prod of the leading dims of attr_matrix), dense A with
+ * S <= 64, 1 <= F, F_out <= 64.  Backward: dW [F, F_out], db [F_out] (overwritten) and, if dX != NULL, dX [n,S,F].
+ * F == F_out == 13 -- the only widths the reference's own model builds (src/main.py:41) -- run the MFMA kernels; other widths
+ * an exact-fp32 kernel of their own (csrc/gcn_any.hip).  Wider layers / more stations: WGNN_ERR_UNSUPPORTED. */
+size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F, int32_t F_out);
+int wgnn_gcn_layer_fwd(int32_t ntiles, int32_t S, int32_t F, int32_t F_out, const float* A, const float* X,
                        const float* W, const float* b, float* out, void* stream);
-int wgnn_gcn_layer_bwd(int32_t ntiles, int32_t S, int32_t F, const float* A, const float* X,
+int wgnn_gcn_layer_bwd(int32_t ntiles, int32_t S, int32_t F, int32_t F_out, const float* A, const float* X,
                        const float* W, const float* out, const float* dout, float* dW, float* db,
                        float* dX, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The recurrent half of GCN_GRU.forward alone (src/step6_gcn_gru_combined_model.py:23: nn.GRU(gru_input, gru_hidden_dim,
+ * batch_first=True), h0 = 0 per window) on a caller-supplied g [B,T,S*13] -- what a GCN_GRU whose input_dim / hidden_dim are
+ * not 13 runs behind two wgnn_gcn_layer_* calls (the fused path's kernels hard-code 13 features, like the reference's
+ * :16).  d: the same dims as for wgnn_fwd with math WGNN_MATH_F32, io WGNN_IO_F32, a dense adjacency format (else
+ * WGNN_ERR_UNSUPPORTED); only p->w_ih, w_hh, b_ih, b_hh are read.  Workspace / stash sizes: wgnn_workspace_bytes /
+ * wgnn_stash_bytes of d.  wgnn_gru_bwd writes the four GRU slots of `grads` (the conv slots may be NULL) and dg [B,T,S*13]. */
+int wgnn_gru_fwd(const wgnn_dims* d, const float* g, const wgnn_params* p, void* Y, void* stash, void* workspace,
+                 size_t workspace_bytes, void* stream);
+int wgnn_gru_bwd(const wgnn_dims* d, const float* g, const wgnn_params* p, const void* Y, const float* dY, const void* stash,
+                 const wgnn_grads* grads, float* dg, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same layer over a CSR adjacency (`csr`: the WGNN_ADJ_CSR buffer described at wgnn_adj_format), any S. */
 size_t wgnn_gcn_layer_csr_workspace_bytes(int32_t ntiles, int32_t S, int32_t F);

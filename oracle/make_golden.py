@@ -62,16 +62,23 @@ def run_reference(model, A, X, L):
     return Y, loss.detach(), grads
 
 
-def make(name, S, T, B, seed, A64, state_dict=None, H=None):
+def make(name, S, T, B, seed, A64, state_dict=None, H=None, dims=None):
+    """dims = (input_dim, hidden_dim): the rest of the constructor's domain (src/step6_gcn_gru_combined_model.py:7-11; output_dim
+    stays 13, which :16 hard-codes); None = the reference's own 13 / 13 (src/main.py:41)."""
     torch.manual_seed(seed)
     H = 3 * S if H is None else H
-    model = GCN_GRU(F, F, F, S * F, H)                       # src/main.py:41-42
+    Fi, Fh = dims if dims is not None else (F, F)
+    model = GCN_GRU(Fi, Fh, F, S * F, H)                     # src/main.py:41-42
     if state_dict is not None:
         model.load_state_dict(state_dict)                    # src/main.py:99
     A = torch.tensor(A64).float()                            # src/main.py:26
     g = torch.Generator().manual_seed(seed + 1)
-    X = torch.rand(B, T, S, F, generator=g)
+    X = torch.rand(B, T, S, Fi, generator=g)
     L = torch.rand(B, T, H, generator=g)
+    if dims is not None:                                     # randn conv weights of other widths: keep the activations O(1)
+        with torch.no_grad():
+            model.conv1.weight.mul_(0.5)
+            model.conv2.weight.mul_(0.5)
     p0 = {k: v.detach().clone() for k, v in model.named_parameters()}
     Y, loss, grads = run_reference(model, A, X, L)
     fx = {"A": A.numpy(), "A64": A64, "X": X.numpy(), "L": L.numpy(), "Y": Y.numpy(),
@@ -90,6 +97,27 @@ def make(name, S, T, B, seed, A64, state_dict=None, H=None):
     np.savez_compressed(path, **fx)
     print("%-28s S=%d T=%d B=%d H=%d loss=%.6f  %.1f KB" % (name, S, T, B, H, loss.item(),
                                                             os.path.getsize(path) / 1024))
+
+
+def make_layer(name, S, lead, Fi, Fo, seed, A64):
+    """One reference GraphConvLayer(Fi, Fo) (src/step5_gcn_layer_model.py:5-23) with input gradient: X [*lead, S, Fi] requires
+    grad, upstream gradient random: out, dW, db, dX."""
+    from step5_gcn_layer_model import GraphConvLayer
+    torch.manual_seed(seed)
+    layer = GraphConvLayer(Fi, Fo)
+    with torch.no_grad():
+        layer.bias.uniform_(-0.5, 0.5)                       # the reference initialises it to zeros (:10): a trained value here
+    A = torch.tensor(A64).float()
+    g = torch.Generator().manual_seed(seed + 1)
+    X = (torch.rand(*lead, S, Fi, generator=g) - 0.3).requires_grad_(True)
+    out = layer(A, X)
+    dout = torch.rand(out.shape, generator=g) - 0.5
+    out.backward(dout)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, A=A.numpy(), X=X.detach().numpy(), W=layer.weight.detach().numpy(), b=layer.bias.detach().numpy(),
+                        out=out.detach().numpy(), dout=dout.numpy(), dW=layer.weight.grad.numpy(), db=layer.bias.grad.numpy(),
+                        dX=X.grad.numpy())
+    print("%-28s S=%d lead=%s %d -> %d  %.1f KB" % (name, S, lead, Fi, Fo, os.path.getsize(path) / 1024))
 
 
 def make_windows_fixture(name, Ttot, S, seq, seed):
@@ -115,10 +143,11 @@ def main():
     only = set(sys.argv[1:])                                  # optional: regenerate just the named fixtures
     os.makedirs(OUT, exist_ok=True)
     if only:
-        global make, make_windows_fixture
-        _make, _mw = make, make_windows_fixture
+        global make, make_windows_fixture, make_layer
+        _make, _mw, _ml = make, make_windows_fixture, make_layer
         make = lambda name, *a, **k: _make(name, *a, **k) if name in only else None                  # noqa: E731
         make_windows_fixture = lambda name, *a, **k: _mw(name, *a, **k) if name in only else None   # noqa: E731
+        make_layer = lambda name, *a, **k: _ml(name, *a, **k) if name in only else None             # noqa: E731
     A7, A34 = ref_adjacency(7), ref_adjacency(34)
     rng = np.random.default_rng(3)
     A3 = rng.random((3, 3)) * 0.5 + 0.05                      # tiny, deliberately asymmetric
@@ -133,6 +162,14 @@ def main():
     make("f4_s34_t168_b1_ckpt", 34, 168, 1, 41, A34, sd34)
     # B = 1 at the 7-station shape: the reference's own call shape (src/main.py:64-80), for the drop-in loop test
     make("f5_s7_t12_b1_rand", 7, 12, 1, 51, A7)
+    # round 5: the constructor's domain beyond 13 / 13 (VERDICT r4 missing 3): GCN_GRU(input_dim, hidden_dim, 13, ...) and single
+    # GraphConvLayer(in, out) layers with input gradients
+    make("f6_s7_t12_b4_in5_hid20", 7, 12, 4, 61, A7, dims=(5, 20))
+    make("f7_s34_t6_b2_in13_hid32", 34, 6, 2, 62, A34, dims=(13, 32))
+    make("f8_s3_t2_b1_in64_hid1", 3, 2, 1, 63, A3, dims=(64, 1))
+    make_layer("l1_s7_in6_out9", 7, (2, 5), 6, 9, 71, A7)
+    make_layer("l2_s34_in13_out40", 34, (3,), 13, 40, 72, A34)
+    make_layer("l3_s3_in64_out64", 3, (1, 4), 64, 64, 73, A3)
     # row N2: windows built by the reference's __create_sequences (src/step4_sequence_preparer.py:7-27)
     make_windows_fixture("w1_t131_s7_seq12", 131, 7, 12, 5)
     make_windows_fixture("w2_t75_s3_seq24", 75, 3, 24, 6)     # len % seq == 3: the last window's labels just fit

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import adjacency_34
-from windgnn_amd import GCN_GRU
+from windgnn_amd import GCN_GRU, _lib
 from windgnn_amd.trainer import TrainStep
 dev = torch.device("cuda:0")
 S, T, H = 34, 168, 102
@@ -32,4 +32,15 @@ for math in ("f32", "f16x3"):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(100): fn()
         torch.cuda.synchronize()
-        print("%-6s %-24s %.0f us/step" % (math, name, (time.perf_counter() - t0) / 100 * 1e6))
+        wall = (time.perf_counter() - t0) / 100 * 1e6
+        # what the step is made of: the library's kernels (hipEvent-bracketed, ~2 us of event latency each), the rest is
+        # launch gaps + (module path) torch's own MSELoss / autograd / Adam kernels and host time
+        _lib.profile_enable(True)
+        for _ in range(20): fn()
+        torch.cuda.synchronize()
+        recs = sorted(_lib.profile_read(), key=lambda r: -r["ms"])
+        _lib.profile_enable(False)
+        ksum = sum(r["ms"] for r in recs) / 20 * 1e3
+        print("%-6s %-24s %.0f us/step; library kernels %.0f us in %d launches/step: %s" % (
+            math, name, wall, ksum, sum(r["launches"] for r in recs) // 20,
+            "  ".join("%s=%.1f" % (r["name"].replace("_kernel", ""), r["ms"] / 20 * 1e3) for r in recs[:9])), flush=True)

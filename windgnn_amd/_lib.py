@@ -75,12 +75,16 @@ EXPORTS = {
                               C.c_size_t, C.c_void_p]),
     "wgnn_prepared_bytes": (C.c_size_t, [C.POINTER(Dims)]),
     "wgnn_prepare_weights": (C.c_int, [C.POINTER(Dims), C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "wgnn_gcn_layer_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
-    "wgnn_gcn_layer_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+    "wgnn_gcn_layer_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "wgnn_gcn_layer_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
-    "wgnn_gcn_layer_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+    "wgnn_gcn_layer_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "wgnn_gru_fwd": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_size_t, C.c_void_p]),
+    "wgnn_gru_bwd": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(Grads), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "wgnn_gcn_layer_csr_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "wgnn_gcn_layer_csr_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -10,7 +10,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libwindgnn_hip.so")
-SOURCES = ["api.hip", "finish.hip", "gcn.hip", "gemm.hip", "gru.hip", "train_ops.hip", "prof.hip", "gcnx.hip", "grux.hip", "pgemm.hip", "data_ops.hip", "general.hip", "gru_small.hip", "gcn32.hip", "gemm32.hip", "gcngi.hip", "pgemm_big.hip"]
+SOURCES = ["api.hip", "finish.hip", "gcn.hip", "gemm.hip", "gru.hip", "train_ops.hip", "prof.hip", "gcnx.hip", "grux.hip", "pgemm.hip", "data_ops.hip", "general.hip", "gru_small.hip", "gcn32.hip", "gemm32.hip", "gcngi.hip", "pgemm_big.hip", "gcn_any.hip"]
 HEADERS = ["common.h", "gcnx_dev.h", os.path.join("..", "..", "include", "windgnn.h")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs, so no v_accvgpr_read per value in the VALU-bound
 # GCN/GRU kernels (gcnx_bwd -8 %).  Safe only because every first read of an MFMA result is a compiler-visible

@@ -44,6 +44,7 @@ struct Layout {
   size_t st_GI;                                  // split modes, register-resident recurrence: GI lives in the stash (BPTT recomputes n from its n third)
   bool gi_stash;
   size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_kp_f, ws_hc, ws_du, ws_dhz, ws_dhw, ws_hhp_b, ws_kp_b, ws_dc;   // general GRU / GCN scratch
+  size_t ws_aimg_f, ws_aimg_b;                   // large-shape NT plane GEMMs (configs[4]): the A operand (g / dGI) rewritten as an image
 };
 
 // (min_rows = 64 measured against 128 / 192 / 256 at B*T = 6144 in round 3: fewer, longer K chunks cost the split-K GEMMs more
@@ -104,6 +105,8 @@ Layout make_layout(const wgnn_dims* d) {
   // is formed -- Y aliases it whenever it fits (H <= Ip: always when H = 3S), and only otherwise gets a region of its own
   if ((x3 && !L.gen_gru) || L.rec32 || L.H <= L.Ip) { L.ws_Ylast = L.ws_g; }
   else { L.ws_Ylast = o; o += al(L.BT * L.H); }
+  // the A operand of the large-shape projection GEMM as an image (pgemm_big.hip): g's two planes, when the shape is one of its
+  L.ws_aimg_f = o; o += al(x3 ? pgemm_nt256_aimg_bytes((int)L.BT, (int)L.G3, (int)L.Ip, 2) / 4 : 0);
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
@@ -182,6 +185,7 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_scales = o; o += al(4096);          // 3 scales, then up to 2 x 1024 block partials from offset 64
   L.ws_dY = o; o += al(L.BT * L.H);          // wgnn_bwd_mse_part outside the fused kernel: dY lives here
   L.ws_xtail_b = o; o += al((L.I & 1) && !L.gen_gcn ? L.I + 1 : 0);
+  L.ws_aimg_b = o; o += al(x3 ? pgemm_nt256_aimg_bytes((int)L.BT, (int)L.I, (int)L.Gp, 2) / 4 : 0);   // dGI's planes as an image (dg GEMM)
   L.bwd_floats = o;
   return L;
 }
@@ -310,7 +314,7 @@ int check_dims(const wgnn_dims* d) {
 
 }  // namespace
 
-bool opt_big_gemm() { return opt(WGNN_OPT_BIG_GEMM) != 0; }
+int opt_big_gemm() { return opt(WGNN_OPT_BIG_GEMM); }
 
 extern "C" {
 
@@ -327,7 +331,7 @@ int wgnn_set_option(int key, int value) {
   if (key == WGNN_OPT_FUSED_FWD && (value < 0 || value > 2)) return WGNN_ERR_SHAPE;
   if ((key == WGNN_OPT_GG_ROLE_SPLIT && (value < 0 || value > 1)) || (key == WGNN_OPT_GG_GEMM_PRIO && (value < 0 || value > 3)))
     return WGNN_ERR_SHAPE;
-  if (key == WGNN_OPT_BIG_GEMM && (value < 0 || value > 1)) return WGNN_ERR_SHAPE;
+  if (key == WGNN_OPT_BIG_GEMM && (value < 0 || value > 2)) return WGNN_ERR_SHAPE;
   if (key == WGNN_OPT_BWD2_CHUNKS && value != 1 && value != 2 && value != 4 && value != WGNN_BWD2_MAX_CHUNKS) return WGNN_ERR_SHAPE;
   init_options();
   return g_opt[key].exchange(value, std::memory_order_relaxed);
@@ -364,17 +368,19 @@ size_t wgnn_stash_bytes(const wgnn_dims* d) {
 
 // last != nullptr (wgnn_fwd_last): no stash; last[B][H] = Y[:, T-1, :] * y_mul + y_add and Y itself is only written
 // where the kernels cannot skip it (into the workspace, for the exact-fp32 and general-shape recurrences).
+// g_in != nullptr (wgnn_gru_fwd): the recurrent half alone on a caller-supplied g [B*T][S*F]; A, X and the conv slots of p unused.
 static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgnn_params* p, const void* labels,
                     void* Y, void* stash, void* workspace, size_t workspace_bytes, void* stream, float* last = nullptr,
-                    float wind_min = 0.f, float wind_max = 1.f) {
+                    float wind_min = 0.f, float wind_max = 1.f, const float* g_in = nullptr) {
   // every read-out path forms its multiplier the same way, (wind_max - wind_min) in fp32, from the caller's two values
   const float y_mul = wind_max - wind_min, y_add = wind_min;
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
-  if (!A || !X || !p || (!Y && !last) || !workspace) return WGNN_ERR_NULL;
-  if (!p->conv1_weight || !p->conv1_bias || !p->conv2_weight || !p->conv2_bias || !p->w_ih || !p->w_hh ||
+  if ((!g_in && (!A || !X)) || !p || (!Y && !last) || !workspace) return WGNN_ERR_NULL;
+  if ((!g_in && (!p->conv1_weight || !p->conv1_bias || !p->conv2_weight || !p->conv2_bias)) || !p->w_ih || !p->w_hh ||
       !p->b_ih || !p->b_hh)
     return WGNN_ERR_NULL;
+  if (g_in && (d->math != WGNN_MATH_F32 || d->io != WGNN_IO_F32 || d->adj_format != WGNN_ADJ_DENSE)) return WGNN_ERR_UNSUPPORTED;
   const Layout L = make_layout(d);
   if (workspace_bytes < sizeof(float) * L.fwd_floats) return WGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -421,8 +427,9 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
                             p->conv2_bias, g, (int)L.Ip, full, status, ws + L.ws_xtail_f, st);
     if (rc != WGNN_OK) return rc;
     const _Float16* ghi = (const _Float16*)g;
+    const size_t aimg_f = pgemm_nt256_aimg_bytes((int)L.BT, (int)L.G3, (int)L.Ip, 2);
     rc = launch_pgemm_nt(ghi, ghi + L.BT * L.Ip, (int)L.Ip, (int)L.BT, (int)L.Ip, img_f, L.np_g3, GI,
-                         (int)L.Gp, (int)L.G3, nullptr, full, nullptr, st, L.gi16);
+                         (int)L.Gp, (int)L.G3, nullptr, full, nullptr, st, L.gi16, aimg_f ? ws + L.ws_aimg_f : nullptr);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gru) {  // any hidden width: one plane GEMM per step against split(W_hh | b_hh)
       rc = launch_split_weight2(p->w_hh, (int)L.G3, (int)L.H, 0, p->b_hh, (int)L.H, ws + L.ws_hhp_f, L.np_g3, (int)L.Hp,
@@ -446,6 +453,8 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
     float* h1 = sf ? sf + L.st_h1 : ws + L.ws_h1;    // layer-1 activations: kept for the backward if there is a stash
     rc = launch_gcn2_csr_fwd((int)L.BT, d->S, d->nnz, A, (const float*)X, p->conv1_weight, p->conv1_bias,
                              p->conv2_weight, p->conv2_bias, h1, g, nullptr, L.Ip, false, nullptr, st);
+  } else if (g_in) {
+    rc = launch_pack_g(g_in, L.BT, (int)L.I, g, (int)L.Ip, st);
   } else {
     rc = launch_gcn32_fwd((int)L.BT, d->S, A, (const float*)X, p->conv1_weight, p->conv1_bias, p->conv2_weight, p->conv2_bias, g,
                          (int)L.Ip, ws + L.ws_xtail_f, st);
@@ -597,9 +606,11 @@ int wgnn_bwd(const wgnn_dims* d, const float* A, const void* X, const wgnn_param
 namespace {
 // The backward behind wgnn_bwd_part (dY given) and wgnn_bwd_mse_part (labels given: dY = 2 (Y - labels) grad_scale / n
 // is never written when the register-resident f16x3 recurrence runs; loss[0] = mean((Y - labels)^2)).
+// dg_out != nullptr (wgnn_gru_bwd): the recurrent half alone -- the four GRU gradients and dg [B*T][S*F]; A, X, the conv slots
+// of p and of g unused.
 int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_params* p, const void* Yv,
              const float* dY, const void* labelsv, float grad_scale, float* loss, const void* stash,
-             const wgnn_grads* g, void* workspace, size_t workspace_bytes, void* stream, int which) {
+             const wgnn_grads* g, void* workspace, size_t workspace_bytes, void* stream, int which, float* dg_out = nullptr) {
   if (which < 1 || which > 31 || (which & 7) == 0) return WGNN_ERR_SHAPE;
   const bool do_rec = which & 1, do_gcn = which & 2, do_wg = which & 4;
   const bool defer = which & WGNN_BWD_DEFER;          // partial sums stay in the workspace for wgnn_finish
@@ -609,11 +620,13 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
   const bool stats_ready = (which & 8) && labels;   // wgnn_fwd_loss left the MSE partials in the stash
   int rc = check_dims(d);
   if (rc != WGNN_OK) return rc;
-  if (!A || !X || !p || !Y || (!dY && !labels) || !stash || !g || !workspace) return WGNN_ERR_NULL;
+  if ((!dg_out && (!A || !X)) || !p || !Y || (!dY && !labels) || !stash || !g || !workspace) return WGNN_ERR_NULL;
   if (labels && do_rec && !loss) return WGNN_ERR_NULL;
-  if (!g->conv1_weight || !g->conv1_bias || !g->conv2_weight || !g->conv2_bias || !g->w_ih || !g->w_hh ||
+  if ((!dg_out && (!g->conv1_weight || !g->conv1_bias || !g->conv2_weight || !g->conv2_bias)) || !g->w_ih || !g->w_hh ||
       !g->b_ih || !g->b_hh)
     return WGNN_ERR_NULL;
+  if (dg_out && (d->math != WGNN_MATH_F32 || d->io != WGNN_IO_F32 || d->adj_format != WGNN_ADJ_DENSE || which != 7))
+    return WGNN_ERR_UNSUPPORTED;
   const Layout L = make_layout(d);
   if (workspace_bytes < sizeof(float) * L.bwd_floats) return WGNN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -730,8 +743,9 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       if (defer) return WGNN_OK;
       return reduce_now(2);
     }
+    const size_t aimg_b = pgemm_nt256_aimg_bytes((int)L.BT, (int)L.I, (int)L.Gp, 2);
     rc = launch_pgemm_nt(dGIh, L.gen_gru ? (L.gen2p ? nullptr : dGIh + PG) : dGIlo, (int)L.Gp, (int)L.BT, (int)L.Gp, img_b, L.np_i, dg, (int)L.Id,
-                         (int)L.I, nullptr, full, nullptr, st, L.dg16);
+                         (int)L.I, nullptr, full, nullptr, st, L.dg16, aimg_b ? ws + L.ws_aimg_b : nullptr);
     if (rc != WGNN_OK) return rc;
     if (L.gen_gcn) {
       rc = launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, nullptr, gact, L.Ip, dg,
@@ -813,6 +827,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
     }
     if (rc != WGNN_OK) return rc;
   }
+  if (dg_out) return launch_unpack_dg(dg, L.BT, (int)L.I, (int)L.Id, dg_out, st);     // wgnn_gru_bwd: hand dg to the caller
   if (L.gen_gcn)
     rc = launch_gcn2_csr_bwd((int)L.BT, d->S, d->nnz, A, X, p->conv2_weight, sf + L.st_h1, gact, nullptr, L.Ip, dg,
                              L.Id, nullptr, ws + L.ws_du, ws + L.ws_gcnpart, nullptr, nullptr, nullptr, nullptr, st);
@@ -841,27 +856,44 @@ int wgnn_bwd_mse_part(const wgnn_dims* d, const float* A, const void* X, const w
                   which);
 }
 
-size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F) {
-  if (ntiles < 1 || S < 1 || S > 64 || F != 13) return 0;
-  return sizeof(float) * gcn1_bwd_partial_floats(ntiles);
+int wgnn_gru_fwd(const wgnn_dims* d, const float* g, const wgnn_params* p, void* Y, void* stash, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  if (!g) return WGNN_ERR_NULL;
+  return fwd_impl(d, nullptr, nullptr, p, nullptr, Y, stash, workspace, workspace_bytes, stream, nullptr, 0.f, 1.f, g);
 }
 
-int wgnn_gcn_layer_fwd(int32_t ntiles, int32_t S, int32_t F, const float* A, const float* X, const float* W,
+int wgnn_gru_bwd(const wgnn_dims* d, const float* g, const wgnn_params* p, const void* Y, const float* dY, const void* stash,
+                 const wgnn_grads* grads, float* dg, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !dY || !dg) return WGNN_ERR_NULL;
+  return bwd_impl(d, nullptr, nullptr, p, Y, dY, nullptr, 1.f, nullptr, stash, grads, workspace, workspace_bytes, stream, 7, dg);
+}
+
+// F == F_out == 13 (the reference's own layers, src/main.py:41): the MFMA kernels of gcn.hip; any other widths: gcn_any.hip
+size_t wgnn_gcn_layer_workspace_bytes(int32_t ntiles, int32_t S, int32_t F, int32_t F_out) {
+  if (ntiles < 1 || !gcn_any_supported(S, F, F_out)) return 0;
+  if (F == 13 && F_out == 13) return sizeof(float) * gcn1_bwd_partial_floats(ntiles);
+  return sizeof(float) * gcn_any_bwd_partial_floats(ntiles, F, F_out);
+}
+
+int wgnn_gcn_layer_fwd(int32_t ntiles, int32_t S, int32_t F, int32_t F_out, const float* A, const float* X, const float* W,
                        const float* b, float* out, void* stream) {
-  if (ntiles < 1 || S < 1 || F != 13) return WGNN_ERR_SHAPE;
-  if (S > 64) return WGNN_ERR_UNSUPPORTED;
+  if (ntiles < 1 || S < 1 || F < 1 || F_out < 1) return WGNN_ERR_SHAPE;
+  if (!gcn_any_supported(S, F, F_out)) return WGNN_ERR_UNSUPPORTED;
   if (!A || !X || !W || !b || !out) return WGNN_ERR_NULL;
-  return launch_gcn1_fwd(ntiles, S, A, X, W, b, out, (hipStream_t)stream);
+  if (F == 13 && F_out == 13) return launch_gcn1_fwd(ntiles, S, A, X, W, b, out, (hipStream_t)stream);
+  return launch_gcn_any_fwd(ntiles, S, F, F_out, A, X, W, b, out, (hipStream_t)stream);
 }
 
-int wgnn_gcn_layer_bwd(int32_t ntiles, int32_t S, int32_t F, const float* A, const float* X, const float* W,
+int wgnn_gcn_layer_bwd(int32_t ntiles, int32_t S, int32_t F, int32_t F_out, const float* A, const float* X, const float* W,
                        const float* out, const float* dout, float* dW, float* db, float* dX, void* workspace,
                        size_t workspace_bytes, void* stream) {
-  if (ntiles < 1 || S < 1 || F != 13) return WGNN_ERR_SHAPE;
-  if (S > 64) return WGNN_ERR_UNSUPPORTED;
+  if (ntiles < 1 || S < 1 || F < 1 || F_out < 1) return WGNN_ERR_SHAPE;
+  if (!gcn_any_supported(S, F, F_out)) return WGNN_ERR_UNSUPPORTED;
   if (!A || !X || !W || !out || !dout || !dW || !db || !workspace) return WGNN_ERR_NULL;
-  if (workspace_bytes < wgnn_gcn_layer_workspace_bytes(ntiles, S, F)) return WGNN_ERR_WORKSPACE;
-  return launch_gcn1_bwd(ntiles, S, A, X, W, out, dout, dW, db, dX, (float*)workspace, (hipStream_t)stream);
+  if (workspace_bytes < wgnn_gcn_layer_workspace_bytes(ntiles, S, F, F_out)) return WGNN_ERR_WORKSPACE;
+  if (F == 13 && F_out == 13)
+    return launch_gcn1_bwd(ntiles, S, A, X, W, out, dout, dW, db, dX, (float*)workspace, (hipStream_t)stream);
+  return launch_gcn_any_bwd(ntiles, S, F, F_out, A, X, W, out, dout, dW, db, dX, (float*)workspace, (hipStream_t)stream);
 }
 
 size_t wgnn_gcn_layer_csr_workspace_bytes(int32_t ntiles, int32_t S, int32_t F) {

@@ -162,11 +162,22 @@ int launch_gcngi_fwd(int ntiles, int S, const float* A, const void* X, int io, c
                      const float* W2, const float* b2, void* g_planes, int ldg, int stash_planes, const void* Bplanes,
                      int Np, void* GI, int ldgi, int N, bool x3, unsigned* status, void* xtail_scratch, hipStream_t st,
                      int role_split = 0, int gemm_prio = 0);
+// GraphConvLayer with any feature widths, S <= 64 dense (gcn_any.hip), and the g / dg hand-over of wgnn_gru_fwd / wgnn_gru_bwd
+bool gcn_any_supported(int S, int Fi, int Fo);
+size_t gcn_any_bwd_partial_floats(int ntiles, int Fi, int Fo);
+int launch_gcn_any_fwd(int ntiles, int S, int Fi, int Fo, const float* A, const float* X, const float* W, const float* b, float* out,
+                       hipStream_t st);
+int launch_gcn_any_bwd(int ntiles, int S, int Fi, int Fo, const float* A, const float* X, const float* W, const float* out,
+                       const float* dout, float* dW, float* db, float* dX, float* partial, hipStream_t st);
+int launch_pack_g(const float* gin, size_t rows, int I, float* g, int ld, hipStream_t st);
+int launch_unpack_dg(const float* dg, size_t rows, int I, int ld, float* out, hipStream_t st);
 // large-shape NT plane GEMM (pgemm_big.hip); opt_big_gemm(): WGNN_OPT_BIG_GEMM (api.hip), 1 unless switched off for an A/B
 bool pgemm_nt256_wanted(int M, int N, int Kp);
 int launch_pgemm_nt256(const void* Ahi, const void* Alo, int lda, int M, int k0, int klen, const void* Bplanes, int Np,
-                       size_t bplane, float* C, int ldc, int N, bool accumulate, hipStream_t st);
-bool opt_big_gemm();
+                       size_t bplane, float* C, int ldc, int N, bool accumulate, hipStream_t st, bool a_image);
+size_t pgemm_nt256_aimg_bytes(int M, int N, int Kp, int planes);
+int launch_pgemm_repack_a(const void* Ahi, const void* Alo, int lda, int M, int Kp, void* img, hipStream_t st);
+int opt_big_gemm();   // 0 off, 1 on (A as an image when the caller gave scratch), 2 on with A row-major
 // ---- The image of a B operand (weights: W_ih | b_ih, W_ih^T, W_hh | b_hh), written by split_weight2_kernel / finish.hip and
 // staged by the NT plane GEMMs and the fused front end: one fp16 plane of B[Np][Kp] is STAGE-major (a 32-deep K step of all
 // Np rows is contiguous) and, since round 5, FRAGMENT-major inside a stage: the 16 rows x 32 k of one MFMA B fragment are 1 KB
@@ -188,7 +199,8 @@ size_t pgemm_tn_partial_floats(int Mout, int Nout, int splitk);
 size_t pgemm_nt_kpart_floats(int M, int ldc, int Kp);
 // out16: C is ONE fp16 plane with row pitch ldc halfs (single-plane A operand only: the x2 and f16 instances)
 int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, const void* Bplanes, int Np, float* C,
-                    int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st, bool out16 = false);
+                    int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st, bool out16 = false,
+                    void* aimg = nullptr /* pgemm_nt256_aimg_bytes() of scratch: lets the large-shape kernel stage A as an image */);
 // A2hi != null: columns m >= msplit of the A operand are column m - msplit of the planes A2hi / A2lo (row stride lda2)
 int launch_pgemm_tn(const void* Ahi, const void* Alo, int lda, const void* Bhi, const void* Blo, int ldb, int shift_T,
                     int K, int splitk, float* partial, int Mout, int Nout, bool x3, const void* A2hi, const void* A2lo,

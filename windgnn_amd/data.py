@@ -59,6 +59,10 @@ def forward_last(model, adj_matrix, attr_matrix: torch.Tensor, wind_min: float, 
     from .functional import _Workspace, _adj, _params_struct
     lib = _lib.load()
     _require_gpu(attr_matrix)
+    if not getattr(model, "fused", True):        # other widths than the reference model's 13 / 13: the module's own forward
+        with torch.no_grad():
+            out = model(adj_matrix, attr_matrix)
+        return predict_last(out if out.dim() == 3 else out.unsqueeze(0), wind_min, wind_max).squeeze(0)
     X = attr_matrix.contiguous()
     B, T, S, F = X.shape
     A, fmt, nnz = _adj(adj_matrix, S)

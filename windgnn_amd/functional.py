@@ -280,7 +280,8 @@ def gcn_gru(A, X, params, math=_lib.MATH_F32):
 
 
 class GraphConvFunction(torch.autograd.Function):
-    """out = relu(A X W + b) for X [..., S, F] (src/step5_gcn_layer_model.py:13-23)."""
+    """out = relu(A X W + b) for X [..., S, F_in], W [F_in, F_out] (src/step5_gcn_layer_model.py:13-23).  Dense adjacency: any
+    widths up to 64 (13 -> 13, the reference model's own, on the MFMA kernels); CSR adjacency: 13 -> 13 only."""
 
     @staticmethod
     def forward(ctx, A, X, W, b):
@@ -288,26 +289,34 @@ class GraphConvFunction(torch.autograd.Function):
         _require_gpu(X, W, b)
         X, W, b = X.contiguous(), W.contiguous(), b.contiguous()
         S, F = X.shape[-2], X.shape[-1]
+        if W.dim() != 2 or W.shape[0] != F or b.shape != (W.shape[1],):
+            # the reference's torch.matmul(adj_attr, self.weight) would fail the same way (step5:18)
+            raise RuntimeError("GraphConvLayer: attr_matrix has %d features but the weight is %s and the bias %s"
+                               % (F, tuple(W.shape), tuple(b.shape)))
+        Fo = W.shape[1]
         A, fmt, nnz = _adj(A, S)
         nt = X.numel() // (S * F)
-        out = torch.empty_like(X)
+        out = torch.empty(*X.shape[:-1], Fo, dtype=X.dtype, device=X.device)
         if fmt == _lib.ADJ_CSR:
+            if (F, Fo) != (13, 13):
+                raise RuntimeError("windgnn_amd: a GraphConvLayer over a CSR adjacency is built for the reference's 13 -> 13 "
+                                   "layers only (got %d -> %d); other widths need a dense adjacency (S <= 64)" % (F, Fo))
             rc = lib.wgnn_gcn_layer_csr_fwd(nt, S, F, nnz, _ptr(A), _ptr(X), _ptr(W), _ptr(b), _ptr(out), _stream())
         else:
-            rc = lib.wgnn_gcn_layer_fwd(nt, S, F, _ptr(A), _ptr(X), _ptr(W), _ptr(b), _ptr(out), _stream())
-        _lib.check(rc, "wgnn_gcn_layer_fwd")
+            rc = lib.wgnn_gcn_layer_fwd(nt, S, F, Fo, _ptr(A), _ptr(X), _ptr(W), _ptr(b), _ptr(out), _stream())
+        _lib.check(rc, "wgnn_gcn_layer_fwd(S=%d, %d -> %d)" % (S, F, Fo))
         ctx.save_for_backward(A, X, W, out)
-        ctx.dims = (nt, S, F, fmt, nnz)
+        ctx.dims = (nt, S, F, Fo, fmt, nnz)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         A, X, W, out = ctx.saved_tensors
-        nt, S, F, fmt, nnz = ctx.dims
+        nt, S, F, Fo, fmt, nnz = ctx.dims
         dout = dout.contiguous()
         dW = torch.empty_like(W)
-        db = torch.empty(F, dtype=torch.float32, device=X.device)
+        db = torch.empty(Fo, dtype=torch.float32, device=X.device)
         dX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
         if fmt == _lib.ADJ_CSR:
             nbytes = lib.wgnn_gcn_layer_csr_workspace_bytes(nt, S, F)
@@ -316,12 +325,57 @@ class GraphConvFunction(torch.autograd.Function):
                                             _ptr(db), _ptr(dX), wsp, nbytes, _stream())
             _lib.check(rc, "wgnn_gcn_layer_csr_bwd")
             return None, dX, dW, db
-        nbytes = lib.wgnn_gcn_layer_workspace_bytes(nt, S, F)
+        nbytes = lib.wgnn_gcn_layer_workspace_bytes(nt, S, F, Fo)
         wsp, _ = _scratch(X.device, nbytes)
-        rc = lib.wgnn_gcn_layer_bwd(nt, S, F, _ptr(A), _ptr(X), _ptr(W), _ptr(out), _ptr(dout), _ptr(dW), _ptr(db),
+        rc = lib.wgnn_gcn_layer_bwd(nt, S, F, Fo, _ptr(A), _ptr(X), _ptr(W), _ptr(out), _ptr(dout), _ptr(dW), _ptr(db),
                                     _ptr(dX), wsp, nbytes, _stream())
         _lib.check(rc, "wgnn_gcn_layer_bwd")
         return None, dX, dW, db
+
+
+class GRUFunction(torch.autograd.Function):
+    """Y [B,T,H] = nn.GRU(I, H, batch_first=True)(g [B,T,I]) with h0 = 0 (src/step6_gcn_gru_combined_model.py:23), through
+    wgnn_gru_fwd / wgnn_gru_bwd: gradients for g and the four GRU tensors.  What GCN_GRU runs behind two GraphConvLayers when its
+    input_dim / hidden_dim are not the reference model's 13 (exact fp32; I must be S * 13: step6:16)."""
+
+    @staticmethod
+    def forward(ctx, g, S, w_ih, w_hh, b_ih, b_hh):
+        lib = _lib.load()
+        _require_gpu(g, w_ih, w_hh, b_ih, b_hh)
+        g = g.contiguous()
+        params = [p.contiguous() for p in (w_ih, w_hh, b_ih, b_hh)]
+        B, T, I = g.shape
+        H = w_hh.shape[1]
+        d = _lib.Dims(B, T, S, 13, H, _lib.MATH_F32, _lib.ADJ_DENSE, 0, _lib.IO_F32)
+        ws_bytes = lib.wgnn_workspace_bytes(C.byref(d))
+        if ws_bytes == 0 or I != S * 13:
+            _lib.check(-5 if I == S * 13 else -2, "wgnn_gru_fwd(B=%d,T=%d,S=%d,I=%d,H=%d)" % (B, T, S, I, H))
+        ws = _Workspace.get(g.device, ws_bytes)
+        need = any(ctx.needs_input_grad)
+        stash = torch.empty(lib.wgnn_stash_bytes(C.byref(d)), dtype=torch.uint8, device=g.device) if need else None
+        Y = torch.empty(B, T, H, dtype=torch.float32, device=g.device)
+        ps = _lib.Params()
+        ps.w_ih, ps.w_hh, ps.b_ih, ps.b_hh = (q.data_ptr() for q in params)
+        _lib.check(lib.wgnn_gru_fwd(C.byref(d), _ptr(g), C.byref(ps), _ptr(Y), _ptr(stash), _ptr(ws), ws_bytes, _stream()),
+                   "wgnn_gru_fwd")
+        ctx.d, ctx.stash = d, stash
+        ctx.save_for_backward(g, Y, *params)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = _lib.load()
+        g, Y, *params = ctx.saved_tensors
+        grads = [torch.empty_like(q) for q in params]
+        dg = torch.empty_like(g)
+        ws_bytes = lib.wgnn_workspace_bytes(C.byref(ctx.d))
+        ws = _Workspace.get(g.device, ws_bytes)
+        ps, gs = _lib.Params(), _lib.Grads()
+        ps.w_ih, ps.w_hh, ps.b_ih, ps.b_hh = (q.data_ptr() for q in params)
+        gs.w_ih, gs.w_hh, gs.b_ih, gs.b_hh = (q.data_ptr() for q in grads)
+        _lib.check(lib.wgnn_gru_bwd(C.byref(ctx.d), _ptr(g), C.byref(ps), _ptr(Y), _ptr(dY.float().contiguous()),
+                                    _ptr(ctx.stash), C.byref(gs), _ptr(dg), _ptr(ws), ws_bytes, _stream()), "wgnn_gru_bwd")
+        return (dg, None, *grads)
 
 
 def mse_loss_grad(Y, L, grad_scale: float = 1.0, want_grad=True):

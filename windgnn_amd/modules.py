@@ -13,17 +13,18 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .functional import GraphConvFunction, check_range_status, gcn_gru
+from .functional import GraphConvFunction, GRUFunction, check_range_status, gcn_gru
 
 NUM_FEATURES = 13   # hard-coded in the reference: src/step6_gcn_gru_combined_model.py:16
 
 
 class GraphConvLayer(nn.Module):
+    """The reference's constructor domain (src/step5_gcn_layer_model.py:6-10): any input_dim -> output_dim.  13 -> 13, the only
+    widths its model builds (src/main.py:41), run the MFMA kernels; other widths (up to 64, dense adjacency of S <= 64) an
+    exact-fp32 kernel of their own; beyond that the forward raises."""
+
     def __init__(self, input_dim, output_dim):
         super().__init__()
-        if input_dim != output_dim:
-            raise RuntimeError("GraphConvLayer: the reference only ever uses input_dim == output_dim "
-                               "(src/main.py:41); got %d -> %d" % (input_dim, output_dim))
         self.weight = nn.Parameter(torch.randn(input_dim, output_dim))   # step5:8-9
         self.bias = nn.Parameter(torch.zeros(output_dim))                # step5:10
 
@@ -56,10 +57,17 @@ class GCN_GRU(nn.Module):
         # validate: in the fp16-plane modes read the library's range-status word after every forward (one 4-byte
         # device-to-host copy) and raise instead of returning inf/NaN-derived values; TrainStep checks every N steps
         self.validate = validate
-        if not (input_dim == hidden_dim == output_dim == NUM_FEATURES):
-            raise RuntimeError("GCN_GRU: the reference hard-codes 13 features per station "
-                               "(src/step6_gcn_gru_combined_model.py:16); got %s"
-                               % ((input_dim, hidden_dim, output_dim),))
+        # The reference's forward flattens conv2's output with a hard-coded 13 (step6:16): output_dim != 13 fails there at the
+        # first call (its .view), here at construction.  input_dim / hidden_dim are free (step6:9-10); at 13 / 13 -- the model
+        # src/main.py:41 builds -- the whole forward / backward is the fused hot path, at other widths it is two general
+        # GraphConvLayers + the recurrent half alone (wgnn_gru_fwd / wgnn_gru_bwd), in exact fp32.
+        if output_dim != NUM_FEATURES:
+            raise RuntimeError("GCN_GRU: output_dim must be 13: forward() flattens conv2's output as num_stations * 13 "
+                               "(src/step6_gcn_gru_combined_model.py:16,20); got output_dim = %d" % output_dim)
+        self.fused = input_dim == NUM_FEATURES and hidden_dim == NUM_FEATURES
+        if not self.fused and math != "f32":
+            raise RuntimeError("GCN_GRU(input_dim=%d, hidden_dim=%d): widths other than 13 run in exact fp32 only "
+                               "(math='f32'), got math=%r" % (input_dim, hidden_dim, math))
         self.conv1 = GraphConvLayer(input_dim, hidden_dim)
         self.conv2 = GraphConvLayer(hidden_dim, output_dim)
         self.gru = _GRUParams(gru_input, gru_hidden_dim)
@@ -74,6 +82,15 @@ class GCN_GRU(nn.Module):
             raise RuntimeError("GCN_GRU.forward: attr_matrix must be [B, T, S, 13], got %s" % (tuple(attr_matrix.shape),))
         B, T, S, F = attr_matrix.shape
         flat = S * NUM_FEATURES
+        if not self.fused:
+            if flat != self.gru.input_size:
+                raise RuntimeError("shape '[%d, %d, %d]' is invalid for input of size %d"
+                                   % (B, T, self.gru.input_size, B * T * flat))
+            hidden1 = self.conv1(adj_matrix, attr_matrix)                               # step6:17
+            hidden2 = self.conv2(adj_matrix, hidden1).view(B, T, flat)                  # step6:20
+            out = GRUFunction.apply(hidden2, S, self.gru.weight_ih_l0, self.gru.weight_hh_l0, self.gru.bias_ih_l0,
+                                    self.gru.bias_hh_l0)                                 # step6:23
+            return out.squeeze(0)                                                        # step6:26
         if F != NUM_FEATURES or flat != self.gru.input_size:
             # mirrors the reference's .view(1, num_seq, flat) failure (step6:20)
             raise RuntimeError("shape '[%d, %d, %d]' is invalid for input of size %d"

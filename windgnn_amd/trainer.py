@@ -37,6 +37,10 @@ class TrainStep:
     def __init__(self, model: GCN_GRU, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group=None, check_every: int = 100, overlap_collectives: bool = False, direct_rccl=None,
                  rccl_loader=None):
+        if not getattr(model, "fused", True):
+            raise RuntimeError("windgnn_amd: TrainStep drives the fused hot path, i.e. the reference model's own widths "
+                               "(input_dim = hidden_dim = 13, src/main.py:41); a GCN_GRU of other widths trains through "
+                               "autograd (loss.backward() + torch.optim.Adam, as src/main.py:66-80 does)")
         self.model = model
         self.params = list(model.hot_path_parameters())
         sizes = [p.numel() for p in self.params]
