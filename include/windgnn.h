@@ -172,9 +172,9 @@ const char* wgnn_strerror(int status);
 #define WGNN_OPT_BWD2_CHUNKS 3
 #define WGNN_BWD2_MAX_CHUNKS 8
 /* 1 (default): NT plane products with >= 1024 rows, >= 2048 columns and a contraction >= 1024 long (BASELINE configs[4]) run
- * the 256 x 256-tile kernel of csrc/pgemm_big.hip with their activation operand rewritten as an image first; 2: the same
- * kernel staging that operand row-major (a measurement aid); 0: the 192 x 448-tile kernel shaped for the 34-station widths.
- * 0 and 1 / 2 sum each dot product in a different order (results differ by fp32 rounding, inside every stated tolerance). */
+ * the 256 x 256-tile kernel of csrc/pgemm_big.hip (their activation operand rewritten as an image first); 0: the 192 x 448-tile
+ * kernel shaped for the 34-station widths.  The two sum each dot product in a different order (results differ by fp32
+ * rounding, inside every stated tolerance). */
 #define WGNN_OPT_BIG_GEMM 4
 #define WGNN_OPT_COUNT 5
 int wgnn_set_option(int key, int value);

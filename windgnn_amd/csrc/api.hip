@@ -44,6 +44,7 @@ struct Layout {
   size_t st_GI;                                  // split modes, register-resident recurrence: GI lives in the stash (BPTT recomputes n from its n third)
   bool gi_stash;
   size_t ws_gh, ws_h1, ws_yp, ws_hhp_f, ws_kp_f, ws_hc, ws_du, ws_dhz, ws_dhw, ws_hhp_b, ws_kp_b, ws_dc;   // general GRU / GCN scratch
+  size_t ws_ntk_f, ws_ntk_b;                     // exact fp32, few rows: split-K partial sums of the GI / dg products
   size_t ws_aimg_f, ws_aimg_b;                   // large-shape NT plane GEMMs (configs[4]): the A operand (g / dGI) rewritten as an image
 };
 
@@ -107,6 +108,10 @@ Layout make_layout(const wgnn_dims* d) {
   else { L.ws_Ylast = o; o += al(L.BT * L.H); }
   // the A operand of the large-shape projection GEMM as an image (pgemm_big.hip): g's two planes, when the shape is one of its
   L.ws_aimg_f = o; o += al(x3 ? pgemm_nt256_aimg_bytes((int)L.BT, (int)L.G3, (int)L.Ip, 2) / 4 : 0);
+  {
+    const int sk = (!x3 && !L.g32 && L.BT < 65536) ? gemm_f32_nt_splitk((int)L.BT, (int)L.G3, (int)L.I) : 1;
+    L.ws_ntk_f = o; o += al(sk > 1 ? (size_t)sk * L.BT * L.G3 : 0);
+  }
   L.fwd_floats = o;
   o = 0;
   L.st_g = o; o += al(L.BT * L.Ip);
@@ -186,6 +191,10 @@ Layout make_layout(const wgnn_dims* d) {
   L.ws_dY = o; o += al(L.BT * L.H);          // wgnn_bwd_mse_part outside the fused kernel: dY lives here
   L.ws_xtail_b = o; o += al((L.I & 1) && !L.gen_gcn ? L.I + 1 : 0);
   L.ws_aimg_b = o; o += al(x3 ? pgemm_nt256_aimg_bytes((int)L.BT, (int)L.I, (int)L.Gp, 2) / 4 : 0);   // dGI's planes as an image (dg GEMM)
+  {
+    const int sk = (!x3 && !L.g32 && L.BT < 65536) ? gemm_f32_nt_splitk((int)L.BT, (int)L.I, (int)L.G3) : 1;
+    L.ws_ntk_b = o; o += al(sk > 1 ? (size_t)sk * L.BT * L.I : 0);
+  }
   L.bwd_floats = o;
   return L;
 }
@@ -331,7 +340,7 @@ int wgnn_set_option(int key, int value) {
   if (key == WGNN_OPT_FUSED_FWD && (value < 0 || value > 2)) return WGNN_ERR_SHAPE;
   if ((key == WGNN_OPT_GG_ROLE_SPLIT && (value < 0 || value > 1)) || (key == WGNN_OPT_GG_GEMM_PRIO && (value < 0 || value > 3)))
     return WGNN_ERR_SHAPE;
-  if (key == WGNN_OPT_BIG_GEMM && (value < 0 || value > 2)) return WGNN_ERR_SHAPE;
+  if (key == WGNN_OPT_BIG_GEMM && (value < 0 || value > 1)) return WGNN_ERR_SHAPE;
   if (key == WGNN_OPT_BWD2_CHUNKS && value != 1 && value != 2 && value != 4 && value != WGNN_BWD2_MAX_CHUNKS) return WGNN_ERR_SHAPE;
   init_options();
   return g_opt[key].exchange(value, std::memory_order_relaxed);
@@ -473,7 +482,8 @@ static int fwd_impl(const wgnn_dims* d, const float* A, const void* X, const wgn
     ga.B = p->w_ih; ga.ldb = (int)L.I; ga.b_kcontig = 1;
     ga.C = GI; ga.ldc = (int)L.Gp; ga.M = (int)L.BT; ga.N = (int)L.G3; ga.K = (int)L.I;
     ga.bias = p->b_ih; ga.splitk = 1;
-    rc = launch_gemm_f32(ga, st);
+    // few rows (the reference's own call shape: 168): split-K + a fixed-order sum, so that more than 15 workgroups work
+    rc = launch_gemm_f32_nt(ga, gemm_f32_nt_splitk(ga.M, ga.N, ga.K) > 1 && L.BT < 65536 ? ws + L.ws_ntk_f : nullptr, st);
   }
   if (rc != WGNN_OK) return rc;
   float* hprev = (sf && L.g32tn) ? sf + L.st_hprev : nullptr;      // [Hprev | 1 | 0..] rows for the backward's dW_hh GEMM
@@ -823,7 +833,7 @@ int bwd_impl(const wgnn_dims* d, const float* A, const void* Xv, const wgnn_para
       c.A = dGI; c.lda = (int)L.Gp; c.a_kcontig = 1;
       c.B = p->w_ih; c.ldb = (int)L.I; c.b_kcontig = 0;
       c.C = dg; c.ldc = (int)L.Id; c.M = (int)L.BT; c.N = (int)L.I; c.K = (int)L.G3; c.splitk = 1;
-      rc = launch_gemm_f32(c, st);
+      rc = launch_gemm_f32_nt(c, gemm_f32_nt_splitk(c.M, c.N, c.K) > 1 && L.BT < 65536 ? ws + L.ws_ntk_b : nullptr, st);
     }
     if (rc != WGNN_OK) return rc;
   }

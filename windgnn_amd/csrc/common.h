@@ -94,6 +94,8 @@ struct GemmArgs {
   float* partial;
 };
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st);
+int gemm_f32_nt_splitk(int M, int N, int K);                          // 1 = no split (enough tiles to fill the chip)
+int launch_gemm_f32_nt(GemmArgs g, float* kpart, hipStream_t st);     // NT product, split-K + fixed-order sum when few rows
 void gemm_f32_tile(int M, int N, int* bm, int* bn);
 int gemm_f32_tiles(int M, int N);
 // gemm32.hip: big-tile exact-fp32 GEMMs for large B*T (operands padded and 16-byte aligned)
@@ -173,11 +175,11 @@ int launch_pack_g(const float* gin, size_t rows, int I, float* g, int ld, hipStr
 int launch_unpack_dg(const float* dg, size_t rows, int I, int ld, float* out, hipStream_t st);
 // large-shape NT plane GEMM (pgemm_big.hip); opt_big_gemm(): WGNN_OPT_BIG_GEMM (api.hip), 1 unless switched off for an A/B
 bool pgemm_nt256_wanted(int M, int N, int Kp);
-int launch_pgemm_nt256(const void* Ahi, const void* Alo, int lda, int M, int k0, int klen, const void* Bplanes, int Np,
-                       size_t bplane, float* C, int ldc, int N, bool accumulate, hipStream_t st, bool a_image);
+int launch_pgemm_nt256(const void* Aimg_hi, const void* Aimg_lo, int M, int k0, int klen, const void* Bplanes, int Np,
+                       size_t bplane, float* C, int ldc, int N, bool accumulate, hipStream_t st);
 size_t pgemm_nt256_aimg_bytes(int M, int N, int Kp, int planes);
 int launch_pgemm_repack_a(const void* Ahi, const void* Alo, int lda, int M, int Kp, void* img, hipStream_t st);
-int opt_big_gemm();   // 0 off, 1 on (A as an image when the caller gave scratch), 2 on with A row-major
+int opt_big_gemm();   // WGNN_OPT_BIG_GEMM: 0 off, 1 on (needs the caller's A-image scratch)
 // ---- The image of a B operand (weights: W_ih | b_ih, W_ih^T, W_hh | b_hh), written by split_weight2_kernel / finish.hip and
 // staged by the NT plane GEMMs and the fused front end: one fp16 plane of B[Np][Kp] is STAGE-major (a 32-deep K step of all
 // Np rows is contiguous) and, since round 5, FRAGMENT-major inside a stage: the 16 rows x 32 k of one MFMA B fragment are 1 KB

@@ -247,6 +247,43 @@ int gemm_f32_tiles(int M, int N) {
   return cdiv_i(M, bm) * cdiv_i(N, bn);
 }
 
+// C[M][ldc] = sum_z partial[z][M][N] (+ bias[n]): the second half of a split-K NT product with few rows (the reference's own
+// call shape, ONE window of 168 steps: 15 workgroups would otherwise each walk all of K; profiles/r5_dropin_latency.txt)
+__global__ void nt_splitk_sum_kernel(const float* __restrict__ partial, int splitk, int M, int N, const float* __restrict__ bias,
+                                     float* __restrict__ C, int ldc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  float s = partial[i];
+  for (int z = 1; z < splitk; ++z) s += partial[(size_t)z * M * N + i];      // fixed order
+  const int n = i % N;
+  C[(size_t)(i / N) * ldc + n] = bias ? s + bias[n] : s;
+}
+
+// Split-K factor for an NT product C[M][N] with a contraction of K: only when the tiles leave most of the chip idle, chunks of
+// at least 64 k, at most 8 of them.  1 = no split.
+int gemm_f32_nt_splitk(int M, int N, int K) {
+  if (gemm_f32_tiles(M, N) >= 64) return 1;
+  int sk = K / 64;
+  return sk < 2 ? 1 : (sk > 8 ? 8 : sk);
+}
+
+// NT product with the split decided by gemm_f32_nt_splitk: `kpart` >= splitk * M * N floats of scratch (unused when 1).
+int launch_gemm_f32_nt(GemmArgs g, float* kpart, hipStream_t st) {
+  const int sk = kpart ? gemm_f32_nt_splitk(g.M, g.N, g.K) : 1;
+  if (sk == 1) { g.splitk = 1; g.partial = nullptr; return launch_gemm_f32(g, st); }
+  const float* bias = g.bias;
+  float* C = g.C;
+  const int ldc = g.ldc;
+  g.splitk = sk; g.partial = kpart; g.bias = nullptr;
+  const int rc = launch_gemm_f32(g, st);
+  if (rc != WGNN_OK) return rc;
+  const int n = g.M * g.N;
+  PROF_LAUNCH("nt_splitk_sum_kernel", 0.0, 4.0 * n * (sk + 1), st,
+              hipLaunchKernelGGL(nt_splitk_sum_kernel, dim3(cdiv_i(n, 256)), dim3(256), 0, st, kpart, sk, g.M, g.N, bias, C, ldc));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
 int launch_gemm_f32(const GemmArgs& g, hipStream_t st) {
   GemmP p;
   p.A = g.A; p.lda = g.lda; p.a_kc = g.a_kcontig;

@@ -663,23 +663,21 @@ int launch_pgemm_nt(const void* Ahi, const void* Alo, int lda, int M, int Kp, co
                     int ldc, int N, const float* s_out, bool x3, float* kpart, hipStream_t st, bool out16, void* aimg) {
   // many rows AND many columns AND a long contraction (configs[4]'s projections): the 256 x 256 / 32x32x16 kernel of
   // pgemm_big.hip, one launch per K chunk (chunk sums added onto C, as below)
-  if (x3 && !out16 && !kpart && !s_out && pgemm_nt256_wanted(M, N, Kp) && Kp % 32 == 0 && lda % 8 == 0 &&
+  if (x3 && !out16 && !kpart && !s_out && aimg && pgemm_nt256_wanted(M, N, Kp) && Kp % 32 == 0 && lda % 8 == 0 &&
       Np >= cdiv_i(N, 256) * 256 && opt_big_gemm()) {
     const int nchunks = nt_chunks(Kp), kc_len = nchunks > 1 ? NT_KC : Kp;
-    const void* ah = Ahi;
-    const void* al = Alo;
-    if (opt_big_gemm() == 2) aimg = nullptr;
-    if (aimg) {       // A as an image: every LDS-DMA piece of it 1 KB contiguous instead of sixteen 64-byte row segments
-      const int rc = launch_pgemm_repack_a(Ahi, Alo, lda, M, Kp, aimg, st);
+    // A as an image (every LDS-DMA piece of it 1 KB contiguous, half stages addressable): one pass over its planes
+    int rc = launch_pgemm_repack_a(Ahi, Alo, lda, M, Kp, aimg, st);
+    if (rc != WGNN_OK) return rc;
+    const void* al = Alo ? (const void*)((const _Float16*)aimg + (size_t)cdiv_i(M, 256) * 256 * Kp) : nullptr;
+    for (int k0 = 0; k0 < Kp;) {
+      int klen = Kp - k0 < kc_len ? Kp - k0 : kc_len;
+      if (Kp - (k0 + klen) < 256) klen = Kp - k0;          // a short tail (Kp = 53 280 = 13 x 4096 + 32) rides with the last full chunk
+      rc = launch_pgemm_nt256(aimg, al, M, k0, klen, Bplanes, Np, (size_t)Np * Kp, C, ldc, N, k0 > 0, st);
       if (rc != WGNN_OK) return rc;
-      ah = aimg;
-      al = Alo ? (const void*)((const _Float16*)aimg + (size_t)cdiv_i(M, 256) * 256 * Kp) : nullptr;
+      k0 += klen;
     }
-    for (int c = 0; c < nchunks; ++c) {
-      const int k0 = c * kc_len, klen = Kp - k0 < kc_len ? Kp - k0 : kc_len;
-      const int rc = launch_pgemm_nt256(ah, al, lda, M, k0, klen, Bplanes, Np, (size_t)Np * Kp, C, ldc, N, c > 0, st, aimg != nullptr);
-      if (rc != WGNN_OK) return rc;
-    }
+    (void)nchunks;
     return WGNN_OK;
   }
   int nsl, T;
