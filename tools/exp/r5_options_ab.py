@@ -43,7 +43,7 @@ if "a" in what:
         fwd = lambda: gcn_gru_forward_raw(A, X, tr.p_views, m.math, want_stash=False, prepared=tr._prepared)
         ref = fwd()[0].clone()
         for rnd in range(2):
-            for split, prio in ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (1, 1), (1, 3)):
+            for split, prio in ((0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (1, 1), (0, 0)):
                 _lib.set_option(_lib.OPT_GG_ROLE_SPLIT, split)
                 _lib.set_option(_lib.OPT_GG_GEMM_PRIO, prio)
                 same = torch.equal(fwd()[0], ref)

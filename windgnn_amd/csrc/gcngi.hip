@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
   constexpr int PL = X3 ? 2 : 1;
   constexpr int RT = R / 16;
   static_assert(R % 16 == 0, "the projection works on 16-row MFMA tiles");
-  static_assert((NG + NM) % 4 == 0 && (4 * NG) % (NG + NM) == 0, "role_split maps roles to whole SIMD slots");
+  constexpr bool CAN_SPLIT = (NG + NM) % 4 == 0 && (4 * NG) % (NG + NM) == 0;   // role_split maps roles to whole SIMD slots
   extern __shared__ __attribute__((aligned(16))) char smem[];
   h8* const sCA = (h8*)smem;                                              // [frag][hi|lo][lane]
   float* const sx = (float*)(smem + (size_t)2 * NF * 64 * 16);            // per GCN wave: [SP][XS] fp32
@@ -58,8 +58,8 @@ __global__ void __launch_bounds__(64 * (NG + NM)) gcngi_fwd_kernel(
   // 3 : 1 -> slot 3 GEMM.  gidx / q: the wave's index inside its role.  The results do not depend on it.
   bool is_gcn = wave < NG;
   int gidx = wave, q = wave - NG;
-  if (role_split) {
-    constexpr int GS = 4 * NG / (NG + NM);                                // SIMD slots that run GCN waves
+  if (CAN_SPLIT && role_split == 1) {
+    constexpr int GS = CAN_SPLIT ? 4 * NG / (NG + NM) : 1;                // SIMD slots that run GCN waves
     const int slot = wave & 3, round = wave >> 2;
     is_gcn = slot < GS;
     gidx = round * GS + slot;
