@@ -9,15 +9,26 @@
 // registers; backward: column j of gate block q, i = q H + j) and the per-step matrix-vector products are plain fp32
 // FMA chains against h / dgh broadcast from LDS: no MFMA tile to fill, ~B workgroups instead of B/16, and a step costs
 // ~H FMAs per thread.  Used when B <= 768; results are fp32 fmaf chains like gru.hip's (different summation order).
+// Round 5: the contraction of a row is split over KSP threads (KSP parts of the workgroup, part p owns k in [p KC, (p + 1) KC),
+// KC = HMAX / KSP; 3 parts at H = 102: 960 threads instead of 320), the parts' sums meet in LDS and the gate phase adds them in
+// a fixed order.  A step was ~2000 cycles of which ~1000 were the 102-long FMA chains of two waves per SIMD (the reference's
+// own call shape, ONE window of 168 steps, spends 73 % of its step in these two kernels: profiles/r5_dropin_latency.txt).
 #include "common.h"
 
 namespace {
 
-constexpr int SMALL_THREADS = 384;   // >= 3 * HMAX for HMAX <= 128
+constexpr int SMALL_THREADS = 1024;  // most threads a workgroup may have: KSP parts of roundup(3 H, 64) threads each
+// Instances: HMAX 32 / 64 / 96 / 108 (H <= 106: three parts of 320 threads) / 112 / 128; parts per instance:
+constexpr int small_ksp(int HMAX) { return HMAX <= 32 ? 1 : ((HMAX == 96 || HMAX == 108) ? 3 : 2); }
+// launch bound of an instance = its largest workgroup (the register budget follows from it: 768 threads = 3 waves per SIMD)
+constexpr int small_threads(int HMAX) {
+  return small_ksp(HMAX) * ((3 * HMAX + 63) / 64 * 64) < SMALL_THREADS ? small_ksp(HMAX) * ((3 * HMAX + 63) / 64 * 64) : SMALL_THREADS;
+}
+static int small_hmax(int H) { return H <= 32 ? 32 : H <= 64 ? 64 : H <= 96 ? 96 : H <= 106 ? 108 : H <= 112 ? 112 : 128; }
 
 // ------------------------------------------------------------------------------------------------
-template <int HMAX, int WPB>
-__global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int T, int H,
+template <int HMAX, int WPB, int KSP>
+__global__ void __launch_bounds__(small_threads(HMAX)) gru_small_fwd_kernel(int B, int T, int H,
                                                                       const float* __restrict__ GI, int ldgi,
                                                                       const float* __restrict__ Whh,
                                                                       const float* __restrict__ bhh,
@@ -43,9 +54,13 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
       for (int c = threadIdx.x; c < H; c += blockDim.x) hprev[(size_t)b * T * hq + c] = 0.f;
     }
   }
+  constexpr int KC = HMAX / KSP;                                     // k extent of one part
+  static_assert(HMAX % KSP == 0 && KC % 4 == 0, "parts of whole 16-byte groups");
   __shared__ __attribute__((aligned(16))) float hs[WPB][HMAX];       // h_{t-1}, zero beyond H
-  __shared__ float ghs[WPB][3 * HMAX];                               // W_hh h + b_hh, gate-major with stride HMAX
-  const int i = threadIdx.x;
+  __shared__ float ghs[KSP][WPB][3 * HMAX];                          // the parts' shares of W_hh h (+ b_hh in part 0), gate-major with stride HMAX
+  const int TP = (int)blockDim.x / KSP;                              // threads per part = roundup(3 H, 64)
+  const int part_id = (int)threadIdx.x / TP, i = (int)threadIdx.x % TP;
+  const int k0 = part_id * KC;
   const int G3 = 3 * H;
   const bool iv = i < G3;
   const int ic = iv ? i : G3 - 1;
@@ -54,7 +69,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
   // cache line (rows are H floats apart): 112 loads x 64 lines per wave, ~33 us per workgroup.  So W_hh comes in
   // linearly (coalesced) through LDS when it fits (3 H^2 floats of dynamic LDS: H <= 108) and each thread picks its
   // row out of the staged copy; larger H takes the strided loads.
-  float w[HMAX];
+  float w[KC];                                                        // this thread's KC elements of its row: k0 .. k0 + KC - 1
   extern __shared__ __attribute__((aligned(16))) float wst[];
   if (stage_w) {
     const int nw = G3 * H;
@@ -65,12 +80,12 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < HMAX; ++k) w[k] = k < H ? wst[ic * H + k] : 0.f;
+    for (int k = 0; k < KC; ++k) w[k] = k0 + k < H ? wst[ic * H + k0 + k] : 0.f;
   } else {
 #pragma unroll
-    for (int k = 0; k < HMAX; ++k) w[k] = k < H ? Whh[(size_t)ic * H + k] : 0.f;
+    for (int k = 0; k < KC; ++k) w[k] = k0 + k < H ? Whh[(size_t)ic * H + k0 + k] : 0.f;
   }
-  const float bh = bhh[ic];
+  const float bh = part_id == 0 ? bhh[ic] : 0.f;
   const int b0 = blockIdx.x * WPB;
   for (int k = threadIdx.x; k < WPB * HMAX; k += blockDim.x) (&hs[0][0])[k] = 0.f;
   // gate phase: thread j < H owns hidden unit j of every window of the workgroup
@@ -101,8 +116,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
       // four independent partial sums (k = 0,1,2,3 mod 4): the FMA chain is 4x shorter than H; fixed order => deterministic
       float a0 = bh, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-      for (int k4 = 0; k4 < HMAX / 4; ++k4) {
-        const f32x4 hv = *(const f32x4*)&hs[wdw][4 * k4];          // same address in every lane: LDS broadcast
+      for (int k4 = 0; k4 < KC / 4; ++k4) {
+        const f32x4 hv = *(const f32x4*)&hs[wdw][k0 + 4 * k4];     // same address in every lane of a part: LDS broadcast
         a0 = fmaf(w[4 * k4 + 0], hv[0], a0);
         a1 = fmaf(w[4 * k4 + 1], hv[1], a1);
         a2 = fmaf(w[4 * k4 + 2], hv[2], a2);
@@ -113,16 +128,22 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
     }
     if (iv) {
 #pragma unroll
-      for (int wdw = 0; wdw < WPB; ++wdw) ghs[wdw][q * HMAX + jq] = acc[wdw];
+      for (int wdw = 0; wdw < WPB; ++wdw) ghs[part_id][wdw][q * HMAX + jq] = acc[wdw];
     }
     __syncthreads();                                // gh complete; every read of h_{t-1} is done
     if (jv) {
 #pragma unroll
       for (int wdw = 0; wdw < WPB; ++wdw) {
         const int b = b0 + wdw;
-        const float ghn = ghs[wdw][2 * HMAX + j];
-        const float rg = sigmoid_fast(gi[wdw][0] + ghs[wdw][j]);      // v_exp / v_rcp forms, |error| < 3e-7 (common.h)
-        const float zg = sigmoid_fast(gi[wdw][1] + ghs[wdw][HMAX + j]);
+        float ghr = ghs[0][wdw][j], ghz = ghs[0][wdw][HMAX + j], ghn = ghs[0][wdw][2 * HMAX + j];
+#pragma unroll
+        for (int pp = 1; pp < KSP; ++pp) {                             // the parts' shares, in a fixed order
+          ghr += ghs[pp][wdw][j];
+          ghz += ghs[pp][wdw][HMAX + j];
+          ghn += ghs[pp][wdw][2 * HMAX + j];
+        }
+        const float rg = sigmoid_fast(gi[wdw][0] + ghr);              // v_exp / v_rcp forms, |error| < 3e-7 (common.h)
+        const float zg = sigmoid_fast(gi[wdw][1] + ghz);
         const float ng = tanh_fast(gi[wdw][2] + rg * ghn);
         const float hnew = (1.f - zg) * ng + zg * hs[wdw][j];
         hs[wdw][j] = hnew;
@@ -175,8 +196,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_fwd_kernel(int B, int
 //   dn = dh (1-z), dz = dh (hprev - n), dnt = dn (1-n^2), dr = dnt gh_n,
 //   dar = dr r (1-r), daz = dz z (1-z);  dgi = [dar, daz, dnt], dgh = [dar, daz, dnt r]
 //   dh_next = dh z + dgh W_hh                       (thread (q, j): sum over gate block q of dgh[q][k] W_hh[qH+k][j])
-template <int HMAX, int WPB>
-__global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int T, int H,
+template <int HMAX, int WPB, int KSP>
+__global__ void __launch_bounds__(small_threads(HMAX)) gru_small_bwd_kernel(int B, int T, int H,
                                                                       const float* __restrict__ Whh,
                                                                       const float* __restrict__ Y,
                                                                       const float* __restrict__ dY,
@@ -204,16 +225,21 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
       if (!tagged && status) atomicOr(status, WGNN_STATUS_NO_LOSS_STATS);
     }
   }
+  constexpr int KC = HMAX / KSP;
+  static_assert(HMAX % KSP == 0 && KC % 4 == 0, "parts of whole 16-byte groups");
   __shared__ __attribute__((aligned(16))) float dghs[WPB][3 * HMAX];  // dgh_t, gate-major with stride HMAX, zero pads
-  __shared__ float part[WPB][3][HMAX];                                 // the three gate blocks' shares of dgh W_hh
-  const int i = threadIdx.x;
+  __shared__ float part[KSP][WPB][3][HMAX];                            // the (k part, gate block) shares of dgh W_hh
+  const int TP = (int)blockDim.x / KSP;
+  const int part_id = (int)threadIdx.x / TP, ip = (int)threadIdx.x % TP;
+  const int k0 = part_id * KC;
   const int G3 = 3 * H;
-  const bool iv = i < G3;
-  const int ic = iv ? i : G3 - 1;
+  const int i = part_id == 0 ? ip : 1 << 20;                           // gate-phase index: only part 0's threads own units
+  const bool iv = ip < G3;
+  const int ic = iv ? ip : G3 - 1;
   const int q = ic / H, j = ic % H;
-  float wT[HMAX];                                                      // W_hh[qH + k][j], k < H
+  float wT[KC];                                                        // W_hh[qH + k0 + k][j]
 #pragma unroll
-  for (int k = 0; k < HMAX; ++k) wT[k] = k < H ? Whh[(size_t)(q * H + k) * H + j] : 0.f;
+  for (int k = 0; k < KC; ++k) wT[k] = k0 + k < H ? Whh[(size_t)(q * H + k0 + k) * H + j] : 0.f;
   const int b0 = blockIdx.x * WPB;
   for (int k = threadIdx.x; k < WPB * 3 * HMAX; k += blockDim.x) (&dghs[0][0])[k] = 0.f;
   {  // zero the K-padding columns [3H, ldd) of this workgroup's dGI / dGH rows
@@ -292,8 +318,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
       for (int wdw = 0; wdw < WPB; ++wdw) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-        for (int k4 = 0; k4 < HMAX / 4; ++k4) {
-          const f32x4 dv = *(const f32x4*)&dghs[wdw][q * HMAX + 4 * k4];
+        for (int k4 = 0; k4 < KC / 4; ++k4) {
+          const f32x4 dv = *(const f32x4*)&dghs[wdw][q * HMAX + k0 + 4 * k4];
           a0 = fmaf(dv[0], wT[4 * k4 + 0], a0);
           a1 = fmaf(dv[1], wT[4 * k4 + 1], a1);
           a2 = fmaf(dv[2], wT[4 * k4 + 2], a2);
@@ -304,14 +330,19 @@ __global__ void __launch_bounds__(SMALL_THREADS) gru_small_bwd_kernel(int B, int
       }
       if (iv) {
 #pragma unroll
-        for (int wdw = 0; wdw < WPB; ++wdw) part[wdw][q][j] = p[wdw];
+        for (int wdw = 0; wdw < WPB; ++wdw) part[part_id][wdw][q][j] = p[wdw];
       }
     }
     __syncthreads();
     if (own && t > 0) {
 #pragma unroll
       for (int wdw = 0; wdw < WPB; ++wdw)
-        dhn[wdw] = dhz[wdw] + ((part[wdw][0][i] + part[wdw][1][i]) + part[wdw][2][i]);
+      {
+        float acc = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < KSP; ++pp) acc += (part[pp][wdw][0][i] + part[pp][wdw][1][i]) + part[pp][wdw][2][i];   // fixed order
+        dhn[wdw] = dhz[wdw] + acc;
+      }
     }
 #pragma unroll
     for (int wdw = 0; wdw < WPB; ++wdw) {
@@ -329,14 +360,19 @@ int pick_wpb(int B) { return 1; }   // 2 and 4 windows per workgroup spill at H 
 // workgroups of 113 + 117 us whatever B <= 4096 is (round 3: register-resident W_hh): the one-window form wins up to ~768
 bool gru_small_supported(int B, int H) { return H >= 1 && H <= 128 && B <= 768; }
 
+#define SMALL_GO(KERNEL, HM, ...) \
+  hipLaunchKernelGGL((KERNEL<HM, 1, small_ksp(HM)>), grid, dim3(small_ksp(HM) * cdiv_i(3 * H, 64) * 64), 0, st, __VA_ARGS__)
 #define SMALL_DISPATCH(KERNEL, ...)                                                                              \
   do {                                                                                                           \
-    const dim3 grid(B), block(cdiv_i(3 * H, 64) * 64);                                                           \
-    if (H <= 32) hipLaunchKernelGGL((KERNEL<32, 1>), grid, block, 0, st, __VA_ARGS__);                           \
-    else if (H <= 64) hipLaunchKernelGGL((KERNEL<64, 1>), grid, block, 0, st, __VA_ARGS__);                      \
-    else if (H <= 96) hipLaunchKernelGGL((KERNEL<96, 1>), grid, block, 0, st, __VA_ARGS__);                      \
-    else if (H <= 112) hipLaunchKernelGGL((KERNEL<112, 1>), grid, block, 0, st, __VA_ARGS__);                    \
-    else hipLaunchKernelGGL((KERNEL<128, 1>), grid, block, 0, st, __VA_ARGS__);                                  \
+    const dim3 grid(B);                                                                                          \
+    switch (small_hmax(H)) {                                                                                     \
+      case 32: SMALL_GO(KERNEL, 32, __VA_ARGS__); break;                                                         \
+      case 64: SMALL_GO(KERNEL, 64, __VA_ARGS__); break;                                                         \
+      case 96: SMALL_GO(KERNEL, 96, __VA_ARGS__); break;                                                         \
+      case 108: SMALL_GO(KERNEL, 108, __VA_ARGS__); break;                                                       \
+      case 112: SMALL_GO(KERNEL, 112, __VA_ARGS__); break;                                                       \
+      default: SMALL_GO(KERNEL, 128, __VA_ARGS__); break;                                                        \
+    }                                                                                                            \
   } while (0)
 
 template <int HMAX>
@@ -346,9 +382,10 @@ static int launch_small_fwd_t(int B, int T, int H, const float* GI, int ldgi, co
   const int stage_w = wbytes <= 140 * 1024;
   const size_t smem = stage_w ? wbytes : 0;
   static std::atomic<unsigned long long> done{0};
-  if (ensure_dyn_smem((const void*)gru_small_fwd_kernel<HMAX, 1>, 140 * 1024, done) != WGNN_OK) return WGNN_ERR_HIP;
-  hipLaunchKernelGGL((gru_small_fwd_kernel<HMAX, 1>), dim3(B), dim3(cdiv_i(3 * H, 64) * 64), smem, st, B, T, H, GI, ldgi,
-                     Whh, bhh, Y, gates, stage_w, hprev, hq, labels, stat_part);
+  constexpr int KSP = small_ksp(HMAX);
+  if (ensure_dyn_smem((const void*)gru_small_fwd_kernel<HMAX, 1, KSP>, 140 * 1024, done) != WGNN_OK) return WGNN_ERR_HIP;
+  hipLaunchKernelGGL((gru_small_fwd_kernel<HMAX, 1, KSP>), dim3(B), dim3(KSP * cdiv_i(3 * H, 64) * 64), smem, st, B, T, H, GI,
+                     ldgi, Whh, bhh, Y, gates, stage_w, hprev, hq, labels, stat_part);
   return WGNN_OK;
 }
 
@@ -359,11 +396,12 @@ int launch_gru_small_fwd(int B, int T, int H, const float* GI, int ldgi, const f
   const double bt = (double)B * T;
   int rc = WGNN_OK;
   PROF_LAUNCH("gru_small_fwd_kernel", bt * 2.0 * 3 * H * H, bt * 4.0 * (3 * H + H + (gates ? 4 * H : 0) + (hprev ? hq : 0)), st,
-              rc = H <= 32   ? launch_small_fwd_t<32>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
-                   : H <= 64 ? launch_small_fwd_t<64>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
-                   : H <= 96 ? launch_small_fwd_t<96>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
-                   : H <= 112 ? launch_small_fwd_t<112>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
-                              : launch_small_fwd_t<128>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st));
+              rc = small_hmax(H) == 32   ? launch_small_fwd_t<32>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                   : small_hmax(H) == 64  ? launch_small_fwd_t<64>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                   : small_hmax(H) == 96  ? launch_small_fwd_t<96>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                   : small_hmax(H) == 108 ? launch_small_fwd_t<108>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                   : small_hmax(H) == 112 ? launch_small_fwd_t<112>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st)
+                                          : launch_small_fwd_t<128>(B, T, H, GI, ldgi, Whh, bhh, Y, gates, hprev, hq, labels, stat_part, st));
   if (rc != WGNN_OK) return rc;
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
