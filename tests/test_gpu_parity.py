@@ -487,9 +487,13 @@ def _oracle_step(A, X, L, p):
 
 
 @pytest.mark.parametrize("math", ["f32", "f16x3"])
-@pytest.mark.parametrize("S,T,B,H,k", [(34, 6, 5, 102, 4), (200, 3, 4, 60, 8), (300, 2, 3, 150, 8), (7, 4, 2, 21, 6)])
+@pytest.mark.parametrize("S,T,B,H,k", [(34, 6, 5, 102, 4), (200, 3, 4, 60, 8), (300, 2, 3, 150, 8), (7, 4, 2, 21, 6),
+                                       (2500, 2, 2, 30, 6), (4501, 1, 2, 24, 5), (1023, 2, 5, 33, 7)])
 def test_csr_adjacency_against_oracle(S, T, B, H, k, math):
-    """k-NN graph in CSR through wgnn_fwd / wgnn_bwd against the dense CPU oracle (S > 64 has no dense path)."""
+    """k-NN graph in CSR through wgnn_fwd / wgnn_bwd against the dense CPU oracle (S > 64 has no dense path).  The SpMM
+    layers (csrc/general.hip) stage their gather source through LDS in chunks of 2048 rows and hand a block 2048 output rows
+    at a time: S = 2500 is two row blocks (2048 + 452) over two chunks, S = 4501 three over three with an odd row length
+    (the scalar copy-out), S = 1023 two whole tiles per block item, S <= 300 groups of 6 ... 292 tiles (ragged last group)."""
     from oracle import windgnn_oracle as orc
     from windgnn_amd.graph import CsrAdjacency, build_knn_adjacency, synthetic_station_coords
     dev = _dev()
@@ -1594,6 +1598,36 @@ def test_backward_part2_in_row_chunks_equals_one_launch(math):
             tol = F16_G_TOL if math == "f16" else G_TOL
             for k in PARAM_KEYS:
                 assert rel_to_max(res[8][2][k], go[k]) <= tol, k
+
+
+def test_exact_fp32_projection_as_two_workgroups_per_cu_is_bitwise_the_one_workgroup_form():
+    """WGNN_OPT_GEMM32_FORM (a schedule option, round 5): the exact-fp32 NT products (GI, dg) from 24 448 rows on as two 4-wave
+    workgroups per CU (128 x 160 tiles; dg's 14 column tiles as slices of 5, 5 and 4) with and without the late start, against
+    the one 8-wave workgroup form: every element is the same fp32 chain, so Y, the loss and all eight gradients are bit-identical;
+    1100 windows x 24 = 26 400 rows leave a ragged last row tile (26 400 = 206 x 128 + 32)."""
+    from oracle import windgnn_oracle as orc
+    from windgnn_amd import _lib
+    dev = _dev()
+    S, T, H = 34, 24, 102
+    p = orc.init_params(S, 13, H, seed=4)
+    g = torch.Generator().manual_seed(77)
+    A = torch.rand(S, S, generator=g) / S + 0.01
+    B = 1100
+    X = torch.rand(B, T, S, 13, generator=g)
+    L = torch.rand(B, T, H, generator=g)
+    res = {}
+    try:
+        for form in (0, 1, 6):
+            _lib.set_option(_lib.OPT_GEMM32_FORM, form)
+            res[form] = _run_step(_model_from(p, S, H, "f32"), A.to(dev), X.to(dev), L.to(dev))
+    finally:
+        _lib.set_option(_lib.OPT_GEMM32_FORM, 0)
+    for form in (1, 6):
+        assert torch.equal(res[0][0], res[form][0]) and res[0][1] == res[form][1]
+        for k in PARAM_KEYS:
+            assert torch.equal(res[0][2][k], res[form][2][k]), (form, k)
+    Yo = orc.forward(A.double(), X[-64:].double(), {k: v.double() for k, v in p.items()}, want_cache=False)[0]
+    assert (res[1][0][-64:].double() - Yo).abs().max().item() <= Y_TOL      # the ragged tile's windows against the fp64 oracle
 
 
 @pytest.mark.parametrize("math,B", [("f16x3", 48), ("f16x3g", 128)])

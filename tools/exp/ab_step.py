@@ -27,7 +27,7 @@ _lib.profile_enable(True)
 for _ in range(20): tr.step(A, X, L)
 torch.cuda.synchronize()
 recs = _lib.profile_read()
-print("step %%.1f us | " %% (dt * 1e6) + " ".join("%%s=%%.1f" %% (r["name"].replace("_kernel", "")[:14], 1e3 * r["ms"] / r["launches"]) for r in recs))
+print("step %%.1f us | " %% (dt * 1e6) + " ".join("%%s=%%.1f" %% (r["name"].replace("_kernel", "")[:22], 1e3 * r["ms"] / r["launches"]) for r in recs))
 ''' % ROOT
 args = sys.argv[1:]
 math, rounds, batch = "f16x3", 2, 4096

@@ -20,7 +20,7 @@ ADJ_CSR = 1
 IO_F32, IO_F16, IO_BF16 = 0, 1, 2   # wgnn_io: element type of X, Y and the labels
 STATUS_BYTES = 256          # WGNN_STATUS_BYTES: status block at the start of every workspace
 OPT_FUSED_FWD = 0           # WGNN_OPT_FUSED_FWD (wgnn_set_option): 0 never / 1 stash-less forwards / 2 every supported forward
-OPT_GG_ROLE_SPLIT, OPT_GG_GEMM_PRIO, OPT_BWD2_CHUNKS, OPT_BIG_GEMM = 1, 2, 3, 4   # measurement aids (include/windgnn.h): same results, another schedule
+OPT_GG_ROLE_SPLIT, OPT_GG_GEMM_PRIO, OPT_BWD2_CHUNKS, OPT_BIG_GEMM, OPT_GEMM32_FORM = 1, 2, 3, 4, 5   # measurement aids (include/windgnn.h): same results, another schedule
 
 
 class Dims(C.Structure):

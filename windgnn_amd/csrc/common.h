@@ -179,6 +179,7 @@ int launch_pgemm_nt256(const void* Aimg_hi, const void* Aimg_lo, int M, int k0, 
                        size_t bplane, float* C, int ldc, int N, bool accumulate, hipStream_t st);
 size_t pgemm_nt256_aimg_bytes(int M, int N, int Kp, int planes);
 int launch_pgemm_repack_a(const void* Ahi, const void* Alo, int lda, int M, int Kp, void* img, hipStream_t st);
+int opt_gemm32_form(); // WGNN_OPT_GEMM32_FORM: 0 one 8-wave workgroup per CU, v >= 1 two 4-wave ones, stagger v - 1 (gemm32.hip)
 int opt_big_gemm();   // WGNN_OPT_BIG_GEMM: 0 off, 1 on (needs the caller's A-image scratch)
 // ---- The image of a B operand (weights: W_ih | b_ih, W_ih^T, W_hh | b_hh), written by split_weight2_kernel / finish.hip and
 // staged by the NT plane GEMMs and the fused front end: one fp16 plane of B[Np][Kp] is STAGE-major (a 32-deep K step of all

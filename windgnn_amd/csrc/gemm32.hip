@@ -11,6 +11,7 @@
 //   TN  P[z][Mo][No] = sum_k A[k][m] B[k][n]  dW_ih|db_ih = dGI^T [g|1], dW_hh|db_hh = dGH^T [Hprev|1]
 //                                              (split-K, reduced by finish.hip)
 #include <string>
+#include <type_traits>
 
 #include "common.h"
 
@@ -31,8 +32,9 @@ constexpr int G_WAVES = 8;      // the TN kernel's and the big NT form's
 
 template <int MW, int NW, int T32>
 __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __restrict__ A, int lda, int M, int Kp,
-                                                               const float* __restrict__ Bp, float* __restrict__ C,
-                                                               int ldc, int N, int nm) {
+                                                               const float* __restrict__ Bp, int nb_rows,
+                                                               float* __restrict__ C, int ldc, int N, int nm, int nsl,
+                                                               int stagger) {
   constexpr int G_BM = 32 * MW, BN = 32 * T32 * NW, NWAVES = MW * NW;
   constexpr int A_BYTES = G_BM * 128, STAGE = A_BYTES + BN * 128;
   constexpr int AP = G_BM / 8, BP = BN / 8;                      // 1 KB pieces: 8 rows x 128 B
@@ -41,8 +43,14 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % MW, wn = wave / MW;
-  const int mt = blockIdx.x % nm, sl = blockIdx.x / nm;
+  // blocks {b, b + 8, ...} share an XCD: the nsl column slices of one row tile are consecutive there, so the tile's rows of A
+  // cross HBM -> L2 once (nsl = 1: the identity)
+  const int bq = blockIdx.x / 8, mt = (bq / nsl) * 8 + blockIdx.x % 8, sl = bq % nsl;
+  if (mt >= nm) return;
   const int m0 = mt * G_BM, n0 = sl * BN;
+  // column tiles of this wave that hold columns of the product (the last slice may be narrower than BN: its dead tiles are
+  // staged from clamped rows and never multiplied)
+  const int tl = NW == 1 ? min(T32, (((N + 31) >> 5) - sl * T32)) : T32;   // T32 or T32 - 1 (launcher)
 
   f32x16 acc[T32];
 #pragma unroll
@@ -65,7 +73,7 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
       const int row = 8 * blk + r8;
       const int chunk = pos ^ ((row >> 1) & 7);
       if (isA) src[it] = A + (size_t)min(m0 + row, M - 1) * lda + 4 * chunk;   // rows past M: computed, never stored
-      else src[it] = Bp + (size_t)(n0 + row) * Kp + 4 * chunk;
+      else src[it] = Bp + (size_t)min(n0 + row, nb_rows - 1) * Kp + 4 * chunk;
       dst[it] = (isA ? 0 : A_BYTES) + blk * 1024;
     }
   }
@@ -77,30 +85,70 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
 
   const int li = lane & 31, kh = lane >> 5, sw = (li >> 1) & 7;
   const int a_row = (32 * wm + li) * 128, b_row = A_BYTES + (32 * T32 * wn + li) * 128;
-  auto compute = [&](const char* cur) {
+  // TL: column tiles multiplied (T32, or T32 - 1 in the narrower last slice of the 4-wave form)
+  auto compute = [&](const char* cur, auto tl_c) {
+    constexpr int TL = decltype(tl_c)::value;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int co = ((2 * kk + kh) ^ sw) << 4;
       const f32x4 a = *(const f32x4*)(cur + a_row + co);
-      f32x4 b[T32];
+      f32x4 b[TL];
 #pragma unroll
-      for (int j = 0; j < T32; ++j) b[j] = *(const f32x4*)(cur + b_row + j * 32 * 128 + co);
+      for (int j = 0; j < TL; ++j) b[j] = *(const f32x4*)(cur + b_row + j * 32 * 128 + co);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int j = 0; j < T32; ++j) acc[j] = mfma32(a[jj], b[j][jj], acc[j]);
+        for (int j = 0; j < TL; ++j) acc[j] = mfma32(a[jj], b[j][jj], acc[j]);
     }
   };
 
+#ifndef G32_ABLATE          // measurement builds only (tools/exp/gemm32_ablate.sh): 1 no C stores, 2 no DMA after the first
+#define G32_ABLATE 0        // stage, 4 no barrier / wait either (the LDS-read + MFMA loop alone)
+#endif
   const int nk = Kp / 32;
   dma_stage(smem, 0);
+  // Two workgroups share a CU in the 4-wave form; the second one of each pair (the dispatcher fills every CU of an XCD once
+  // before it comes back: blocks 256 ... 511 of the first 512) starts `stagger` x 3.4 us late, so that from then on one
+  // workgroup's epilogue and first stage fall into the other's K loop -- and the chip's C stores do not come as one burst.
+  if (stagger > 0 && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();        // stage kt visible to all waves, stage kt-1 no longer being read
-    if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kt + 1);
-    compute(smem + (kt & 1) * STAGE);
+    if (!(G32_ABLATE & 4)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();        // stage kt visible to all waves, stage kt-1 no longer being read
+    }
+    if (!(G32_ABLATE & 2) && kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kt + 1);
+    if (T32 == 1 || tl == T32) compute(smem + (kt & 1) * STAGE, std::integral_constant<int, T32>{});
+    else compute(smem + (kt & 1) * STAGE, std::integral_constant<int, (T32 > 1 ? T32 - 1 : 1)>{});
+  }
+  if (G32_ABLATE & 1) {      // keep the accumulators alive without the stores
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < T32; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[j][r];
+    if (t == 1234.5678f) C[0] = t;
+    return;
   }
 
+#ifndef G32_STORE
+#define G32_STORE 0
+#endif
+  if (G32_STORE & 1) {       // row-major order: a row's T32 x 128 B go out back to back
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+#pragma unroll
+      for (int j = 0; j < T32; ++j) {
+        const int col = n0 + 32 * T32 * wn + 32 * j + li;
+        if (col < N && row < M) {
+          if (G32_STORE & 2) __builtin_nontemporal_store(acc[j][r], C + (size_t)row * ldc + col);
+          else C[(size_t)row * ldc + col] = acc[j][r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < T32; ++j) {
     const int col = n0 + 32 * T32 * wn + 32 * j + li;
@@ -108,7 +156,10 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (row < M) C[(size_t)row * ldc + col] = acc[j][r];
+      if (row < M) {
+        if (G32_STORE & 2) __builtin_nontemporal_store(acc[j][r], C + (size_t)row * ldc + col);
+        else C[(size_t)row * ldc + col] = acc[j][r];
+      }
     }
   }
 }
@@ -260,8 +311,9 @@ bool nt_big(int M) { return cdiv_i(M, 128) >= 192; }
 
 template <int MW, int NW, int T32>
 int launch_nt_t(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, int nsl,
-                hipStream_t st) {
+                hipStream_t st, int stagger = 0) {
   const int nm = cdiv_i(M, 32 * MW);
+  const int nb_rows = gemm32_nt_rows(N);
   const size_t smem = 2 * (size_t)(32 * MW + 32 * T32 * NW) * 128;
   static std::atomic<unsigned long long> done{0};
   if (ensure_dyn_smem((const void*)gemm32_nt_kernel<MW, NW, T32>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
@@ -269,8 +321,8 @@ int launch_nt_t(const float* A, int lda, int M, int Kp, const float* Bp, float* 
   const double fl = 2.0 * M * (double)N * Kp;
   const double by = 4.0 * ((double)M * Kp + (double)N * Kp + (double)M * N);
   PROF_LAUNCH(name.c_str(), fl, by, st,
-              hipLaunchKernelGGL((gemm32_nt_kernel<MW, NW, T32>), dim3(nm * nsl), dim3(64 * MW * NW), smem, st, A, lda,
-                                 M, Kp, Bp, C, ldc, N, nm));
+              hipLaunchKernelGGL((gemm32_nt_kernel<MW, NW, T32>), dim3(cdiv_i(nm, 8) * 8 * nsl), dim3(64 * MW * NW), smem,
+                                 st, A, lda, M, Kp, Bp, nb_rows, C, ldc, N, nm, nsl, stagger));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -334,6 +386,18 @@ int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, fl
   int nsl, T;
   nt_shape(N, big, nsl, T);
   if (Kp % 32 != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bp & 15)) return WGNN_ERR_SHAPE;
+  const int form = opt_gemm32_form();
+  if (big && form > 0) {
+    // two 4-wave workgroups per CU: 128 x 32 T tiles with T <= 5 (2 x 72 KB of LDS), the N range cut into equal slices of whole
+    // 32-column tiles (the last one may hold fewer)
+    const int t32 = cdiv_i(N, 32), ns2 = cdiv_i(t32, 5), T2 = cdiv_i(t32, ns2);
+    if (ns2 * T2 - t32 <= 1) switch (T2) {     // the kernel's last slice may be one tile short, not more
+#define NT_CASE(t) \
+  case t: return launch_nt_t<4, 1, t>(A, lda, M, Kp, Bp, C, ldc, N, ns2, st, form - 1);
+      NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5)
+#undef NT_CASE
+    }
+  }
   if (big) {
     switch (T) {
 #define NT_CASE(t) \

@@ -18,7 +18,6 @@ constexpr int F13 = 13;
 constexpr int FP = 16;
 constexpr int PART = 2 * FP * FP + 2 * FP;   // same partial layout as gcn.hip: dW1 | dW2 | db1 | db2
 constexpr int ROWS = 256;                    // stations per block
-constexpr int GEN_BLOCKS = 1024;             // persistent backward blocks = partial rows
 
 struct Csr {
   const int* rowptr;
@@ -26,7 +25,7 @@ struct Csr {
   const float* val;
 };
 
-// p[f] = sum_e val[e] * V[col[e]][f] over row s, in CSR order
+// p[f] = sum_e val[e] * V[col[e]][f] over row s, in CSR order (csr_spmm_kernel: the one-layer API's dX)
 __device__ __forceinline__ void spmv_row(const Csr& c, int s, const float* __restrict__ V, float (&p)[F13]) {
 #pragma unroll
   for (int f = 0; f < F13; ++f) p[f] = 0.f;
@@ -39,125 +38,350 @@ __device__ __forceinline__ void spmv_row(const Csr& c, int s, const float* __res
   }
 }
 
-// Out[tile][s][:] = relu((A In[tile])[s][:] W + b).  PLANES: the output row is written as fp16 hi/lo planes
-// [ntiles][ld_out] (the f16x3 interchange format, pgemm.hip) with 1.0 in column S*13 and zeros behind it.
-template <bool PLANES>
-__global__ void __launch_bounds__(ROWS) csr_layer_fwd_kernel(int ntiles, int S, Csr A, const float* __restrict__ In,
-                                                             size_t ld_in, const float* __restrict__ W,
-                                                             const float* __restrict__ b, float* __restrict__ Out,
-                                                             size_t ld_out, _Float16* __restrict__ Ohi,
-                                                             _Float16* __restrict__ Olo, unsigned* status) {
-  bool bad = false;
-  __shared__ float Ws[F13 * F13], bs[F13];
-  for (int i = threadIdx.x; i < F13 * F13; i += ROWS) Ws[i] = W[i];
-  if (threadIdx.x < F13) bs[threadIdx.x] = b[threadIdx.x];
-  __syncthreads();
-  const int s = blockIdx.x * ROWS + threadIdx.x;
-  const int I = S * F13;
-  for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
-    if (PLANES && blockIdx.x == 0)                    // the ones column and the padding behind it
-      for (int c = I + threadIdx.x; c < (int)ld_out; c += ROWS) {
-        Ohi[(size_t)tile * ld_out + c] = (_Float16)(c == I ? 1.f : 0.f);
-        if (Olo) Olo[(size_t)tile * ld_out + c] = (_Float16)0.f;
-      }
-    if (s >= S) continue;
-    float p[F13];
-    spmv_row(A, s, In + (size_t)tile * ld_in, p);
+// ---- LDS-tiled SpMM layers --------------------------------------------------------------------------------------------
+// One 1024-thread block per CU.  A block item is a set of up to RPT * 1024 output rows that share one gather source: a row
+// block of one tile (S >= RPT * 1024) or the rows of floor(RPT * 1024 / S) consecutive tiles (smaller graphs; their [S][13]
+// inputs are contiguous in memory, so the group is one [ng * S][13] matrix and tile g's columns are offset by g * S).  The
+// source is staged through LDS in chunks of CH = 2048 rows padded to 16 floats (128 KB; coalesced 16-byte global loads),
+// and every thread walks the CSR rows it owns once per chunk, gathering the neighbours that fall into the chunk with four
+// ds_read_b128 each: the scattered 52-byte reads that bound the thread-per-row kernel of rounds 1-4 on the texture path (64
+// cache lines per wave instruction: 2.0 ms per layer at S = 4096, 128 windows) hit LDS banks instead.  With S <= CH the sum
+// runs in CSR order; beyond that in chunk order (CSR order inside a chunk) -- fixed either way.
+constexpr int CT = 1024;                  // threads per block
+constexpr int CH = 2048;                  // source rows per LDS chunk
+constexpr int CSR_BLOCKS = 256;           // persistent blocks (= partial rows of the backward)
+constexpr size_t CSR_LDS = ((size_t)CH * 16 + 256) * sizeof(float);       // chunk | W (169) | b (13)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct CsrItem {
+  int tile0, ng, row0, nrows, VC;         // first tile, tiles in the group, first row, output rows, source rows
+};
+// item -> rows; RB = rows per item
+__device__ __forceinline__ CsrItem csr_item(int item, int ntiles, int S, int RB) {
+  CsrItem it;
+  if (S >= RB) {
+    const int nrb = (S + RB - 1) / RB;
+    it.tile0 = item / nrb;
+    it.ng = 1;
+    it.row0 = (item - it.tile0 * nrb) * RB;
+    it.nrows = min(RB, S - it.row0);
+    it.VC = S;
+  } else {
+    const int G = RB / S;
+    it.tile0 = item * G;
+    it.ng = min(G, ntiles - it.tile0);
+    it.row0 = 0;
+    it.nrows = it.ng * S;
+    it.VC = it.nrows;
+  }
+  return it;
+}
+// items of a launch (host and device); ntiles * row blocks stays far below 2^31 (api.hip bounds B * T)
+__host__ __device__ inline int csr_items(int ntiles, int S, int RB) {
+  return S >= RB ? ntiles * ((S + RB - 1) / RB) : (ntiles + RB / S - 1) / (RB / S);
+}
+
+// p[q][:] = sum over the CSR entries [e0[q], e1[q]) of val * src[col + coff[q]][:], src = [VC][13] contiguous.
+template <int RPT, int NB = 4>
+__device__ __forceinline__ void csr_gather(const Csr& c, const float* __restrict__ src, int VC, const int (&e0)[RPT],
+                                           const int (&e1)[RPT], const int (&coff)[RPT], float* tile,
+                                           float (&p)[RPT][F13]) {
 #pragma unroll
-    for (int c = 0; c < F13; ++c) {
-      float a = bs[c];
+  for (int q = 0; q < RPT; ++q)
 #pragma unroll
-      for (int f = 0; f < F13; ++f) a = fmaf(p[f], Ws[f * F13 + c], a);
-      a = fmaxf(a, 0.f);
-      const size_t o = (size_t)tile * ld_out + (size_t)s * F13 + c;
-      if (PLANES) {
-        bad |= out_of_fp16_range(a);
-        const _Float16 h = (_Float16)a;
-        Ohi[o] = h;
-        if (Olo) Olo[o] = (_Float16)(a - (float)h);
+    for (int f = 0; f < F13; ++f) p[q][f] = 0.f;
+  for (int c0 = 0; c0 < VC; c0 += CH) {
+    const int nr = min(CH, VC - c0), nf = nr * F13;
+    const float* s0 = src + (size_t)c0 * F13;
+    __syncthreads();                                   // whatever the buffer held has been consumed
+    for (int j = 4 * (int)threadIdx.x; j < nf; j += 4 * CT) {
+      if (j + 3 < nf) {
+        const f32x4u v = *(const f32x4u*)(s0 + j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned jj = (unsigned)(j + k), row = jj / F13;
+          tile[row * 16 + (jj - row * F13)] = v[k];
+        }
       } else {
-        Out[o] = a;
+        for (int k = 0; j + k < nf; ++k) {
+          const unsigned jj = (unsigned)(j + k), row = jj / F13;
+          tile[row * 16 + (jj - row * F13)] = s0[jj];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      for (int e = e0[q]; e < e1[q]; e += NB) {        // NB column indices per round trip
+        int cc[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) cc[k] = e + k < e1[q] ? c.col[e + k] + coff[q] - c0 : -1;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          if ((unsigned)cc[k] < (unsigned)nr) {
+            const float v = c.val[e + k];
+            const f32x4* x = (const f32x4*)(tile + cc[k] * 16);
+            const f32x4 x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+              p[q][f] = fmaf(v, x0[f], p[q][f]);
+              p[q][4 + f] = fmaf(v, x1[f], p[q][4 + f]);
+              p[q][8 + f] = fmaf(v, x2[f], p[q][8 + f]);
+            }
+            p[q][12] = fmaf(v, x3[0], p[q][12]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// The q-th row a thread owns is row v = tid + CT q of the item: tile it.tile0 + g, CSR row s (recomputed where needed: a
+// division is cheaper than two live registers per row next to the 13-wide accumulators)
+__device__ __forceinline__ bool csr_row_of(const CsrItem& it, int S, int q, int& g, int& srow) {
+  const int v = (int)threadIdx.x + CT * q;
+  g = it.ng == 1 ? 0 : v / S;
+  srow = it.row0 + v - g * S;
+  return v < it.nrows;
+}
+template <int RPT>
+__device__ __forceinline__ void csr_rows(const Csr& c, const CsrItem& it, int S, int (&e0)[RPT], int (&e1)[RPT],
+                                         int (&coff)[RPT]) {
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    int g, srow;
+    const bool ok = csr_row_of(it, S, q, g, srow);
+    const int sc = ok ? srow : 0;                              // rows past the item: an empty range (unconditional loads)
+    e0[q] = c.rowptr[sc];
+    e1[q] = ok ? c.rowptr[sc + 1] : e0[q];
+    coff[q] = ok ? g * S : 0;
+  }
+}
+
+// Out[tile][s][:] = relu((A In[tile])[s][:] W + b); In = [ntiles][S*13].  PLANES: the output row is written as fp16 hi/lo
+// planes [ntiles][ld_out] (the f16x3 interchange format, pgemm.hip) with 1.0 in column S*13 and zeros behind it.  The rows go
+// through LDS once more on their way out, so that the stores are whole 16-byte (planes: 8-byte) pieces of consecutive memory.
+template <bool PLANES>
+__global__ void __launch_bounds__(CT) csr_layer_fwd_kernel(int ntiles, int S, Csr A, const float* __restrict__ In,
+                                                           const float* __restrict__ W, const float* __restrict__ b,
+                                                           float* __restrict__ Out, size_t ld_out,
+                                                           _Float16* __restrict__ Ohi, _Float16* __restrict__ Olo,
+                                                           unsigned* status) {
+#ifndef CSR_FWD_RPT
+#define CSR_FWD_RPT 2
+#endif
+#ifndef CSR_FWD_NB
+#define CSR_FWD_NB 4
+#endif
+  constexpr int RPT = CSR_FWD_RPT, RB = CT * RPT;              // output rows per item
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile = lds;
+  float* Ws = lds + CH * 16;
+  float* bs = Ws + 176;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < F13 * F13; i += CT) Ws[i] = W[i];
+  if (tid < F13) bs[tid] = b[tid];
+  bool bad = false;
+  const int I = S * F13;
+  const bool vec = (I & 3) == 0 && (ld_out & 3) == 0;
+  const int nitems = csr_items(ntiles, S, RB);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const CsrItem it = csr_item(item, ntiles, S, RB);
+    float p[RPT][F13];
+    {
+      int e0[RPT], e1[RPT], coff[RPT];
+      csr_rows<RPT>(A, it, S, e0, e1, coff);
+      csr_gather<RPT, CSR_FWD_NB>(A, In + (size_t)it.tile0 * I, it.VC, e0, e1, coff, tile, p);
+    }
+#pragma unroll
+    for (int h = 0; h < (RPT + 1) / 2; ++h) {                   // 2 CT rows at a time go out through LDS as [row][13]
+      if (h * 2 * CT >= it.nrows) break;                       // block-uniform
+      __syncthreads();                                         // the last chunk / the previous rows have been read
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int q = 2 * h + qq;
+        if (q >= RPT || tid + CT * q >= it.nrows) continue;
+        float* o = tile + (size_t)(tid + CT * qq) * F13;
+#pragma unroll
+        for (int c = 0; c < F13; ++c) {
+          float a = bs[c];
+#pragma unroll
+          for (int f = 0; f < F13; ++f) a = fmaf(p[q < RPT ? q : 0][f], Ws[f * F13 + c], a);
+          o[c] = fmaxf(a, 0.f);
+        }
+      }
+      __syncthreads();
+      const int lo = h * 2 * CT * F13, hi = min(it.nrows, (h + 1) * 2 * CT) * F13;   // linear elements of the item's output
+      auto dst_of = [&](int j) -> size_t {                     // element j of the item -> offset in Out / the planes
+        if (it.ng == 1) return (size_t)it.tile0 * ld_out + (size_t)it.row0 * F13 + j;
+        const int g = j / I;
+        return (size_t)(it.tile0 + g) * ld_out + (j - g * I);
+      };
+      if (vec) {
+        for (int j = lo + 4 * tid; j < hi; j += 4 * CT) {
+          const f32x4 v = *(const f32x4*)(tile + (j - lo));
+          const size_t d = dst_of(j);
+          if (PLANES) {
+            f16x4 vh, vl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              bad |= out_of_fp16_range(v[k]);
+              vh[k] = (_Float16)v[k];
+              vl[k] = (_Float16)(v[k] - (float)vh[k]);
+            }
+            *(f16x4*)(Ohi + d) = vh;
+            if (Olo) *(f16x4*)(Olo + d) = vl;
+          } else {
+            *(f32x4*)(Out + d) = v;
+          }
+        }
+      } else {
+        for (int j = lo + tid; j < hi; j += CT) {
+          const float a = tile[j - lo];
+          const size_t d = dst_of(j);
+          if (PLANES) {
+            bad |= out_of_fp16_range(a);
+            const _Float16 hh = (_Float16)a;
+            Ohi[d] = hh;
+            if (Olo) Olo[d] = (_Float16)(a - (float)hh);
+          } else {
+            Out[d] = a;
+          }
+        }
+      }
+    }
+    if (PLANES && it.row0 == 0) {                              // the ones column and the padding behind it
+      const int padw = (int)ld_out - I;
+      for (int j = tid; j < it.ng * padw; j += CT) {
+        const int g = j / padw, c = I + j - g * padw;
+        const size_t d = (size_t)(it.tile0 + g) * ld_out + c;
+        Ohi[d] = (_Float16)(c == I ? 1.f : 0.f);
+        if (Olo) Olo[d] = (_Float16)0.f;
       }
     }
   }
   if (PLANES) report_status(status, bad, WGNN_STATUS_ACT_RANGE);
 }
 
-// One backward layer for a block's share of (tile, row-block) items:
-//   dz = dOut * (Out > 0)           where dOut is given directly (layer 2: dg) or as A^T DU (layer 1)
+// One backward layer:
+//   dz = dOut * (Out > 0)           where dOut is given directly (layer 2: dg) or as A^T DU (layer 1: gathered like A In)
 //   p  = (A In)[s]                  (recomputed aggregation)
-//   dW += p^T dz, db += dz          (per-block partials, fixed order)
+//   dW += p^T dz, db += dz          on v_mfma_f32_16x16x4_f32: the rows' p (with a ones column: db) and dz go through LDS as
+//                                   [row][16] and every wave contracts its 64 rows in 16 MFMAs; the fp32 accumulator tile is
+//                                   added into fp64 registers after every 64 rows (these are long sums of mixed-sign terms,
+//                                   cancellation ~100x at S = 4096) and reduced over the block's waves at the end
 //   DU[tile][s][:] = dz W^T         (layer 2 only: what layer 1's A^T product consumes)
 template <bool LAYER2>
-__global__ void __launch_bounds__(ROWS) csr_layer_bwd_kernel(int ntiles, int S, Csr A, Csr AT,
-                                                             const float* __restrict__ In, size_t ld_in,
-                                                             const float* __restrict__ Out,
-                                                             const _Float16* __restrict__ Out_hi, size_t ld_out,
-                                                             const float* __restrict__ dOut, size_t ld_dout,
-                                                             const float* __restrict__ W, float* __restrict__ DU,
-                                                             const float* __restrict__ scales,
-                                                             float* __restrict__ partial) {
-  __shared__ float Ws[F13 * F13];
-  __shared__ float ps[ROWS][F13], dzs[ROWS][F13];
-  const int tid = threadIdx.x;
-  if (LAYER2)
-    for (int i = tid; i < F13 * F13; i += ROWS) Ws[i] = W[i];
-  const int nrb = (S + ROWS - 1) / ROWS;
-  const long long nitems = (long long)ntiles * nrb;
-  // thread t < 169: dW[t/13][t%13]; 169 <= t < 182: db[t-169].  fp64: these are long sums of mixed-sign terms
-  // (cancellation ~100x at S = 4096) and the loop is far off the critical path.
-  double acc = 0.0;
-  for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int tile = (int)(item / nrb), s = (int)(item % nrb) * ROWS + tid;
-    float p[F13], dz[F13];
-    if (s < S) {
-      const size_t oo = (size_t)tile * ld_out + (size_t)s * F13;
-      bool on[F13];                                           // ReLU mask: fp32 activations or their fp16 hi plane
+__global__ void __launch_bounds__(CT) csr_layer_bwd_kernel(int ntiles, int S, Csr A, Csr AT,
+                                                           const float* __restrict__ In,
+                                                           const float* __restrict__ Out,
+                                                           const _Float16* __restrict__ Out_hi, size_t ld_out,
+                                                           const float* __restrict__ dOut, size_t ld_dout,
+                                                           const float* __restrict__ W, float* __restrict__ DU,
+                                                           const float* __restrict__ scales,
+                                                           float* __restrict__ partial) {
+  constexpr int RPT = 2, RB = CT * RPT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile = lds;
+  float* Ws = lds + CH * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (LAYER2) {
+    for (int i = tid; i < F13 * F13; i += CT) Ws[i] = W[i];
+    __syncthreads();
+  }
+  const int I = S * F13;
+  double acc64[4] = {0.0, 0.0, 0.0, 0.0};      // lane (c = lane & 15, g = lane >> 4), r: dW[f = 4 g + r][c]; f = 13: db[c]
+  const int nitems = csr_items(ntiles, S, RB);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const CsrItem it = csr_item(item, ntiles, S, RB);
+    int e0[RPT], e1[RPT], coff[RPT];
+    float dz[RPT][F13], p[RPT][F13];
+    if (!LAYER2) {                                             // dH1 = A^T DU (DU = dOut, [ntiles][S*13])
+      csr_rows<RPT>(AT, it, S, e0, e1, coff);
+      csr_gather<RPT, 2>(AT, dOut + (size_t)it.tile0 * I, it.VC, e0, e1, coff, tile, dz);
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      int g, srow;
+      if (!csr_row_of(it, S, q, g, srow)) {
+#pragma unroll
+        for (int f = 0; f < F13; ++f) dz[q][f] = 0.f;
+        continue;
+      }
+      const size_t oo = (size_t)(it.tile0 + g) * ld_out + (size_t)srow * F13;
+      bool on[F13];                                            // ReLU mask: fp32 activations or their fp16 hi plane
 #pragma unroll
       for (int f = 0; f < F13; ++f) on[f] = Out_hi ? (float)Out_hi[oo + f] > 0.f : Out[oo + f] > 0.f;
       if (LAYER2) {
-        const float* d = dOut + (size_t)tile * ld_dout + (size_t)s * F13;
+        const float* d = dOut + (size_t)(it.tile0 + g) * ld_dout + (size_t)srow * F13;
 #pragma unroll
-        for (int f = 0; f < F13; ++f) dz[f] = on[f] ? d[f] : 0.f;
+        for (int f = 0; f < F13; ++f) dz[q][f] = on[f] ? d[f] : 0.f;
       } else {
-        spmv_row(AT, s, dOut + (size_t)tile * ld_dout, dz);   // dH1 = A^T DU
 #pragma unroll
-        for (int f = 0; f < F13; ++f) dz[f] = on[f] ? dz[f] : 0.f;
-      }
-      spmv_row(A, s, In + (size_t)tile * ld_in, p);
-    } else {
-#pragma unroll
-      for (int f = 0; f < F13; ++f) p[f] = dz[f] = 0.f;
-    }
-    __syncthreads();   // previous item's outer product is done (and Ws is loaded)
-#pragma unroll
-    for (int f = 0; f < F13; ++f) {
-      ps[tid][f] = p[f];
-      dzs[tid][f] = dz[f];
-    }
-    if (LAYER2 && s < S) {
-      float* du = DU + ((size_t)tile * S + s) * F13;
-#pragma unroll
-      for (int f = 0; f < F13; ++f) {
-        float a = 0.f;
-#pragma unroll
-        for (int c = 0; c < F13; ++c) a = fmaf(dz[c], Ws[f * F13 + c], a);
-        du[f] = a;
+        for (int f = 0; f < F13; ++f) dz[q][f] = on[f] ? dz[q][f] : 0.f;
       }
     }
-    __syncthreads();
-    if (tid < F13 * F13) {
-      const int f = tid / F13, c = tid % F13;
-      for (int r = 0; r < ROWS; ++r) acc += (double)ps[r][f] * (double)dzs[r][c];
-    } else if (tid < F13 * F13 + F13) {
-      const int c = tid - F13 * F13;
-      for (int r = 0; r < ROWS; ++r) acc += (double)dzs[r][c];
+    if (LAYER2) {
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        int g, srow;
+        if (!csr_row_of(it, S, q, g, srow)) continue;
+        float* du = DU + ((size_t)(it.tile0 + g) * S + srow) * F13;
+#pragma unroll
+        for (int f = 0; f < F13; ++f) {
+          float a = 0.f;
+#pragma unroll
+          for (int c = 0; c < F13; ++c) a = fmaf(dz[q][c], Ws[f * F13 + c], a);
+          du[f] = a;
+        }
+      }
+    }
+    csr_rows<RPT>(A, it, S, e0, e1, coff);
+    csr_gather<RPT, 2>(A, In + (size_t)it.tile0 * I, it.VC, e0, e1, coff, tile, p);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      if (q * CT >= it.nrows) break;                           // block-uniform
+      __syncthreads();                                         // the chunk / the previous rows' operands have been read
+      f32x4* P = (f32x4*)(tile + (size_t)tid * 16);
+      f32x4* Z = (f32x4*)(tile + (size_t)(CT + tid) * 16);
+      const bool live = tid + CT * q < it.nrows;                 // rows past the item: p = dz = 0 too
+      const float one = live ? 1.f : 0.f;
+      P[0] = f32x4{live ? p[q][0] : 0.f, live ? p[q][1] : 0.f, live ? p[q][2] : 0.f, live ? p[q][3] : 0.f};
+      P[1] = f32x4{live ? p[q][4] : 0.f, live ? p[q][5] : 0.f, live ? p[q][6] : 0.f, live ? p[q][7] : 0.f};
+      P[2] = f32x4{live ? p[q][8] : 0.f, live ? p[q][9] : 0.f, live ? p[q][10] : 0.f, live ? p[q][11] : 0.f};
+      P[3] = f32x4{live ? p[q][12] : 0.f, one, 0.f, 0.f};
+      Z[0] = f32x4{dz[q][0], dz[q][1], dz[q][2], dz[q][3]};
+      Z[1] = f32x4{dz[q][4], dz[q][5], dz[q][6], dz[q][7]};
+      Z[2] = f32x4{dz[q][8], dz[q][9], dz[q][10], dz[q][11]};
+      Z[3] = f32x4{dz[q][12], 0.f, 0.f, 0.f};
+      __syncthreads();
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* pr = tile + (size_t)(64 * wave + (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc = mfma16(pr[j * 64], pr[CT * 16 + j * 64], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc64[r] += (double)acc[r];
     }
   }
-  if (scales) acc *= (double)scales[1];   // dOut arrives in the backward's power-of-two scaled units
-  float* mine = partial + (size_t)blockIdx.x * PART;
-  if (tid < F13 * F13) mine[(LAYER2 ? FP * FP : 0) + (tid / F13) * FP + tid % F13] = (float)acc;
-  else if (tid < F13 * F13 + F13) mine[2 * FP * FP + (LAYER2 ? FP : 0) + tid - F13 * F13] = (float)acc;
+  // ---- block reduction in wave order, one partial row per block
+  __syncthreads();
+  double* red = (double*)lds;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(size_t)wave * 256 + lane * 4 + r] = acc64[r];
+  __syncthreads();
+  if (tid < 256) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < CT / 64; ++w) t += red[w * 256 + tid];
+    if (scales) t *= (double)scales[1];      // dOut arrives in the backward's power-of-two scaled units
+    const int l = tid >> 2, r = tid & 3, f = 4 * (l >> 4) + r, c = l & 15;
+    float* mine = partial + (size_t)blockIdx.x * PART;
+    if (c < F13) {
+      if (f < F13) mine[(LAYER2 ? FP * FP : 0) + f * FP + c] = (float)t;
+      else if (f == F13) mine[2 * FP * FP + (LAYER2 ? FP : 0) + c] = (float)t;
+    }
+  }
 }
 
 // ---- GRU cell, forward: one thread per (window, hidden unit) -----------------------------------
@@ -331,28 +555,43 @@ Csr csr_of(const void* blob, int S, int nnz, bool transposed) {
 
 }  // namespace
 
-size_t gcn_csr_bwd_partial_floats() { return (size_t)GEN_BLOCKS * PART; }
+size_t gcn_csr_bwd_partial_floats() { return (size_t)CSR_BLOCKS * PART; }
 
 // g: fp32 [ntiles][ldg], or (g_planes != nullptr) fp16 hi/lo planes [ntiles][ldg] each (lo skipped if !x3)
+// opt the three LDS-tiled kernels into their 129 KB of dynamic LDS (once per device)
+static int csr_lds_ready() {
+  static std::atomic<unsigned long long> d0{0}, d1{0}, d2{0}, d3{0};
+  int rc = ensure_dyn_smem((const void*)csr_layer_fwd_kernel<false>, CSR_LDS, d0);
+  if (rc == WGNN_OK) rc = ensure_dyn_smem((const void*)csr_layer_fwd_kernel<true>, CSR_LDS, d1);
+  if (rc == WGNN_OK) rc = ensure_dyn_smem((const void*)csr_layer_bwd_kernel<false>, CSR_LDS, d2);
+  if (rc == WGNN_OK) rc = ensure_dyn_smem((const void*)csr_layer_bwd_kernel<true>, CSR_LDS, d3);
+  return rc;
+}
+static int csr_grid(int ntiles, int S, int rpt) {
+  const int n = csr_items(ntiles, S, CT * rpt);
+  return n < CSR_BLOCKS ? (n < 1 ? 1 : n) : CSR_BLOCKS;
+}
+
 int launch_gcn2_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W1, const float* b1,
                         const float* W2, const float* b2, float* h1, float* g, void* g_planes, size_t ldg, bool x3,
                         unsigned* status, hipStream_t st) {
   const Csr A = csr_of(csr, S, nnz, false);
-  const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
+  if (csr_lds_ready() != WGNN_OK) return WGNN_ERR_HIP;
+  const dim3 grid(csr_grid(ntiles, S, CSR_FWD_RPT));
   const double fl = (double)ntiles * (2.0 * nnz * F13 + 2.0 * S * F13 * F13), by = (double)ntiles * S * F13 * 8.0;
   const size_t I = (size_t)S * F13;
   PROF_LAUNCH("csr_layer_fwd_kernel", fl, by, st,
-              hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(ROWS), 0, st, ntiles, S, A, X, I, W1, b1, h1, I,
+              hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(CT), CSR_LDS, st, ntiles, S, A, X, W1, b1, h1, I,
                                  (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr));
   WGNN_CHECK_LAUNCH();
   if (g_planes) {
     _Float16* hi = (_Float16*)g_planes;
     PROF_LAUNCH("csr_layer_fwd_kernel", fl, by, st,
-                hipLaunchKernelGGL(csr_layer_fwd_kernel<true>, grid, dim3(ROWS), 0, st, ntiles, S, A, h1, I, W2, b2,
+                hipLaunchKernelGGL(csr_layer_fwd_kernel<true>, grid, dim3(CT), CSR_LDS, st, ntiles, S, A, h1, W2, b2,
                                    (float*)nullptr, ldg, hi, x3 ? hi + (size_t)ntiles * ldg : (_Float16*)nullptr, status));
   } else {
     PROF_LAUNCH("csr_layer_fwd_kernel", fl, by, st,
-                hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(ROWS), 0, st, ntiles, S, A, h1, I, W2, b2, g,
+                hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(CT), CSR_LDS, st, ntiles, S, A, h1, W2, b2, g,
                                    ldg, (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr));
   }
   WGNN_CHECK_LAUNCH();
@@ -368,20 +607,22 @@ int launch_gcn2_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float
   const Csr A = csr_of(csr, S, nnz, false), AT = csr_of(csr, S, nnz, true);
   const size_t I = (size_t)S * F13;
   const double fl = (double)ntiles * (2.0 * nnz * F13 + 4.0 * S * F13 * F13), by = (double)ntiles * S * F13 * 16.0;
+  if (csr_lds_ready() != WGNN_OK) return WGNN_ERR_HIP;
+  // every block writes its partial row (zeros if it had no item): always CSR_BLOCKS blocks
   PROF_LAUNCH("csr_layer_bwd_kernel<2>", fl, by, st,
-              hipLaunchKernelGGL((csr_layer_bwd_kernel<true>), dim3(GEN_BLOCKS), dim3(ROWS), 0, st, ntiles, S, A, AT, h1,
-                                 I, g, (const _Float16*)g_hi, ldg, dg, ld_dg, W2, du, scales, partial));
+              hipLaunchKernelGGL((csr_layer_bwd_kernel<true>), dim3(CSR_BLOCKS), dim3(CT), CSR_LDS, st, ntiles, S, A, AT, h1,
+                                 g, (const _Float16*)g_hi, ldg, dg, ld_dg, W2, du, scales, partial));
   WGNN_CHECK_LAUNCH();
   PROF_LAUNCH("csr_layer_bwd_kernel<1>", fl + (double)ntiles * 2.0 * nnz * F13, by, st,
-              hipLaunchKernelGGL((csr_layer_bwd_kernel<false>), dim3(GEN_BLOCKS), dim3(ROWS), 0, st, ntiles, S, A, AT, X,
-                                 I, h1, (const _Float16*)nullptr, I, du, I, (const float*)nullptr, (float*)nullptr,
+              hipLaunchKernelGGL((csr_layer_bwd_kernel<false>), dim3(CSR_BLOCKS), dim3(CT), CSR_LDS, st, ntiles, S, A, AT, X,
+                                 h1, (const _Float16*)nullptr, I, du, I, (const float*)nullptr, (float*)nullptr,
                                  scales, partial));
   WGNN_CHECK_LAUNCH();
   if (!dW1) return WGNN_OK;              // deferred: finish.hip reduces the gcn_csr_bwd_rows() partial rows
-  return launch_gcn_partial_reduce(partial, GEN_BLOCKS, dW1, db1, dW2, db2, nullptr, st);
+  return launch_gcn_partial_reduce(partial, CSR_BLOCKS, dW1, db1, dW2, db2, nullptr, st);
 }
 
-int gcn_csr_bwd_rows() { return GEN_BLOCKS; }
+int gcn_csr_bwd_rows() { return CSR_BLOCKS; }
 
 // Y, gates from GI: per step gh = Hprev W_hh^T + b_hh (GEMM, skipped at t = 0 where h = 0) and the cell.
 int launch_gru_gen_fwd(int B, int T, int H, const float* GI, int ldgi, const float* Whh, const float* bhh, float* Y,
@@ -485,10 +726,10 @@ size_t gcn1_csr_bwd_ws_floats(int ntiles, int S) { return (size_t)ntiles * S * F
 int launch_gcn1_csr_fwd(int ntiles, int S, int nnz, const void* csr, const float* X, const float* W, const float* b,
                         float* out, hipStream_t st) {
   const Csr A = csr_of(csr, S, nnz, false);
-  const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
+  if (csr_lds_ready() != WGNN_OK) return WGNN_ERR_HIP;
   const size_t I = (size_t)S * F13;
-  hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, grid, dim3(ROWS), 0, st, ntiles, S, A, X, I, W, b, out, I,
-                     (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr);
+  hipLaunchKernelGGL(csr_layer_fwd_kernel<false>, dim3(csr_grid(ntiles, S, CSR_FWD_RPT)), dim3(CT), CSR_LDS, st, ntiles, S, A, X, W, b,
+                     out, I, (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr);
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
 }
@@ -500,10 +741,11 @@ int launch_gcn1_csr_bwd(int ntiles, int S, int nnz, const void* csr, const float
   const size_t I = (size_t)S * F13;
   float* du = ws;
   float* partial = ws + (size_t)ntiles * I;
-  hipLaunchKernelGGL((csr_layer_bwd_kernel<true>), dim3(GEN_BLOCKS), dim3(ROWS), 0, st, ntiles, S, A, AT, X, I, out,
+  if (csr_lds_ready() != WGNN_OK) return WGNN_ERR_HIP;
+  hipLaunchKernelGGL((csr_layer_bwd_kernel<true>), dim3(CSR_BLOCKS), dim3(CT), CSR_LDS, st, ntiles, S, A, AT, X, out,
                      (const _Float16*)nullptr, I, dout, I, W, du, (const float*)nullptr, partial);
   WGNN_CHECK_LAUNCH();
-  int rc = launch_gcn_partial_reduce(partial, GEN_BLOCKS, nullptr, nullptr, dW, db, nullptr, st);   // the "layer 2" slots
+  int rc = launch_gcn_partial_reduce(partial, CSR_BLOCKS, nullptr, nullptr, dW, db, nullptr, st);   // the "layer 2" slots
   if (rc != WGNN_OK || !dX) return rc;
   const dim3 grid(cdiv_i(S, ROWS), ntiles < 16384 ? ntiles : 16384);
   hipLaunchKernelGGL(csr_spmm_kernel, grid, dim3(ROWS), 0, st, ntiles, S, AT, du, dX);

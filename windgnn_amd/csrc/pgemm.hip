@@ -514,25 +514,46 @@ __global__ void __launch_bounds__(64 * TN_WAVES) pgemm_tn_kernel(const _Float16*
 
 // Planes of O[Rp][Cp] (O[r][c] = transpose ? W[c][r] : W[r][c]; optional extra column `bias_col`
 // holding bias[r]; zero elsewhere) from fp32 W[R][C], in the B-image layout bimg_off(r, c, Rp) (common.h): stage-major, and
-// fragment-major inside a stage.  Thread i writes element i of the image (coalesced stores).
+// fragment-major inside a stage.  Thread i writes the i-th 16-byte piece of each plane -- 8 consecutive k of one image row --
+// so a wavefront stores 1 KB of consecutive memory per plane and (not transposed) reads 16 W rows x 128 consecutive bytes.
+// (One 2-byte store per thread, rounds 1-5a: 2.2 ms for each 36 864 x 12 288 image of BASELINE configs[4], 1.65 TB/s.)
 __global__ void split_weight2_kernel(const float* __restrict__ W, int R, int C, int transpose,
                                      const float* __restrict__ bias, int bias_col, _Float16* hi, _Float16* lo,
                                      int Rp, int Cp, unsigned* status) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Rp * Cp) return;
-  const int tile = i >> 9, within = i & 511;                      // 1 KB fragments: [K step][16-row tile][k chunk][row][8]
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  const size_t pi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= (size_t)Rp * Cp / 8) return;
+  const int tile = (int)(pi >> 6), within = (int)(pi & 63);       // 1 KB fragments: [K step][16-row tile][k chunk][row][8]
   const int kt = tile / (Rp >> 4), nt = tile % (Rp >> 4);
-  const int r = 16 * nt + ((within >> 3) & 15), c = 32 * kt + 8 * (within >> 7) + (within & 7);
-  float v = 0.f;
-  if (transpose) { if (c < R && r < C) v = W[(size_t)c * C + r]; }
-  else {
-    if (r < R && c < C) v = W[(size_t)r * C + c];
-    else if (bias && r < R && c == bias_col) v = bias[r];
+  const int r = 16 * nt + (within & 15), c0 = 32 * kt + 8 * (within >> 4);
+  float v[8];
+  if (transpose) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (c0 + k < R && r < C) ? W[(size_t)(c0 + k) * C + r] : 0.f;
+  } else if (r < R && c0 + 7 < C && (((size_t)r * C + c0) & 3) == 0) {
+    const f32x4 a = *(const f32x4*)(W + (size_t)r * C + c0), b = *(const f32x4*)(W + (size_t)r * C + c0 + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + k;
+      v[k] = 0.f;
+      if (r < R && c < C) v[k] = W[(size_t)r * C + c];
+      else if (bias && r < R && c == bias_col) v[k] = bias[r];
+    }
   }
-  const _Float16 h = (_Float16)v;
-  hi[i] = h;
-  lo[i] = (_Float16)(v - (float)h);
-  report_status(status, out_of_fp16_range(v), WGNN_STATUS_WEIGHT_RANGE);
+  h8v vh, vl;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    bad |= out_of_fp16_range(v[k]);
+    vh[k] = (_Float16)v[k];
+    vl[k] = (_Float16)(v[k] - (float)vh[k]);
+  }
+  *(h8v*)(hi + pi * 8) = vh;
+  *(h8v*)(lo + pi * 8) = vl;
+  report_status(status, bad, WGNN_STATUS_WEIGHT_RANGE);
 }
 
 }  // namespace
@@ -541,9 +562,10 @@ int launch_split_weight2(const float* W, int R, int C, int transpose, const floa
                          int Rp, int Cp, unsigned* status, hipStream_t st) {
   _Float16* hi = (_Float16*)planes;
   _Float16* lo = hi + (size_t)Rp * Cp;
-  const int n = Rp * Cp;
-  PROF_LAUNCH("split_weight2_kernel", 0.0, 4.0 * R * C + 4.0 * n, st,
-              hipLaunchKernelGGL(split_weight2_kernel, dim3(cdiv_i(n, 256)), dim3(256), 0, st, W, R, C, transpose,
+  const size_t n8 = (size_t)Rp * Cp / 8;
+  if ((Rp & 15) || (Cp & 31) || (((uintptr_t)planes | ((size_t)Rp * Cp * 2)) & 15)) return WGNN_ERR_SHAPE;
+  PROF_LAUNCH("split_weight2_kernel", 0.0, 4.0 * R * C + 4.0 * (double)Rp * Cp, st,
+              hipLaunchKernelGGL(split_weight2_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, W, R, C, transpose,
                                  bias, bias_col, hi, lo, Rp, Cp, status));
   WGNN_CHECK_LAUNCH();
   return WGNN_OK;
