@@ -15,6 +15,7 @@ GPU does not enter the timed region cold); (3) `warmup` untimed steps + exactly 
 mode on the same workload (secondary value); (5) the CPU baselines."""
 import argparse
 import json
+import re
 import os
 import shutil
 import subprocess
@@ -42,9 +43,15 @@ BOUND_HBM_PREFIXES = ("mse_", "adam_", "finish_", "amax_", "splitk_reduce", "tn_
 
 
 def committed_traffic():
-    """Fallback only: the newest committed PMC summary (profiles/*traffic*.json), or ({}, None)."""
+    """Fallback only: the newest committed PMC summary of the TRAINING STEP (profiles/rN_x_traffic.json; the forward-only
+    summaries `*_fwd_only_*_traffic.json` hold other launch counts), or ({}, None).  Newest = highest round tag, not mtime
+    (a checkout gives every file the same time)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), key=os.path.getmtime, reverse=True):
+    paths = [q for q in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")) if "fwd_only" not in os.path.basename(q)]
+    def tag(q):                                          # "r5_b_traffic.json" -> (5, "b")
+        m = re.match(r"r(\d+)_([a-z]+)_", os.path.basename(q))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    for path in sorted(paths, key=tag, reverse=True):
         try:
             return json.load(open(path))["kernels"], os.path.basename(path)
         except Exception:
