@@ -42,6 +42,9 @@ F16X3G_GRAD_ERR = {"mse_step_B4096": 2.0e-6, "strict_f16x3_same_test": 9.6e-7, "
 BOUND_HBM_PREFIXES = ("mse_", "adam_", "finish_", "amax_", "splitk_reduce", "tn_reduce", "split_weight", "gcn_partial", "csr_", "gru_cell")
 
 
+SPINUP_STEPS = int(os.environ.get("WGNN_BENCH_SPINUP", "60"))   # untimed steps in front of the W warm-up steps (the GPU's clock ramp after an idle gap: see main())
+
+
 def committed_traffic():
     """Fallback only: the newest committed PMC summary of the TRAINING STEP (profiles/rN_x_traffic.json; the forward-only
     summaries `*_fwd_only_*_traffic.json` hold other launch counts), or ({}, None).  Newest = highest round tag, not mtime
@@ -193,7 +196,7 @@ def check_stashless_forward(A, X, L, trainer, math):
 
 
 def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
-    """One more configuration timed on the same box: `nsteps` full training steps (TrainStep.step) after 10 warm-up steps,
+    """One more configuration timed on the same box: `nsteps` full training steps (TrainStep.step) after 50 warm-up steps,
     inputs resident; with `forward` also the forward-only time against its own algorithmic bytes (X + Y in the I/O type)."""
     from windgnn_amd import GCN_GRU
     from windgnn_amd.functional import gcn_gru_forward_raw
@@ -202,7 +205,7 @@ def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
     m = GCN_GRU(F, F, F, S * F, H, math=math).to(dev)
     tr = TrainStep(m)
     X, L = make_inputs(B, 0, dev, S, H, io)
-    for _ in range(10):                                  # first launches of this mode's kernels + clocks
+    for _ in range(10 + SPINUP_STEPS):                   # first launches of this mode's kernels + the clock ramp (see main())
         tr.step(A, X, L)
     torch.cuda.synchronize()
     s0 = time.perf_counter()
@@ -217,7 +220,9 @@ def secondary_config(math, io, B, A, dev, nsteps, note, forward=False):
     if forward:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         check_stashless_forward(A, X, L, tr, m.math)
-        for _ in range(20):                             # untimed (after the check's host sync): first launches, clocks
+        for _ in range(SPINUP_STEPS):                   # untimed, after the check's host sync: the clock ramp (see main())
+            tr.step(A, X, L)
+        for _ in range(20):                             # untimed: first launches of the stash-less forward's own kernels
             gcn_gru_forward_raw(A, X, tr.p_views, m.math, want_stash=False, prepared=tr._prepared)
         nfwd = max(nsteps, 50)
         e0.record()
@@ -395,33 +400,58 @@ def main():
         torch.cuda.synchronize()
         recs = _lib.profile_read()
         _lib.profile_enable(False)
-        check_stashless_forward(A, X, L, trainer, model.math)   # what is timed below is the training forward's Y, bit for bit
-        # (the check ends in a host synchronisation: the GPU idles and drops its clocks, so the untimed calls come AFTER it, and
-        # nothing below synchronises with the host again before the contract's own barrier in front of the timed steps -- the
-        # forward's events are read after the timed region.  A sync right in front of a 5 ms timed loop read 261-269 us for this
-        # forward against 220 in a 200-step run: profiles/r5_bench_short_run_idle_gap.txt)
+        check_stashless_forward(A, X, L, trainer, model.math)   # what is timed further down is the training forward's Y, bit for bit
         for _ in range(20):     # untimed: the stash-less forward runs kernels the training step does not (first launch, code load)
             gcn_gru_forward_raw(A, X, trainer.p_views, model.math, want_stash=False, prepared=trainer._prepared)
+        # (the forward itself is timed AFTER the timed steps, on a GPU they have just kept busy: the check above ends in a host
+        # synchronisation, the GPU idles and drops its clocks, and a short loop right behind it read 225-269 us for a forward that
+        # takes 207-212 in a 200-step run: profiles/r5_bench_short_run_idle_gap.txt, r5_b_clock_ramp.txt)
+
+    n_global = world * B                                # fixed global batch: the exchange needs no count collective
+    import gc
+    gc.collect()                                        # (tens of ms of host time: BEFORE the spin-up, or the GPU idles again)
+    gc.disable()                                        # no collector pause inside a 15 ms timed region (as timeit does)
+    if not args.traffic_child:
+        # Untimed spin-up on every rank, before the contract's own W warm-up steps: the checks above synchronise with the host,
+        # the GPU idles for a few ms and drops its clocks, and it takes ~25 training steps (20 ms) of load to get them back
+        # (per-step times after a 5 ms idle gap: 773 794 822 848 860 852 830 808 ... 753 us against 745 steady:
+        # profiles/r5_b_clock_ramp.txt).  With --steps 20 --warmup 5 the timed region would otherwise sit inside that ramp.
+        nspin = SPINUP_STEPS if args.workload == "c3" else 2              # (a configs[4] step is 140 ms: two are a ramp's worth)
+        spin_ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        spin_ev[0].record()
+        for i in range(nspin):
+            trainer.step(A, X, L, n_global)
+            if i + 1 == nspin // 2:
+                spin_ev[1].record()
+        spin_ev[2].record()
+    for _ in range(args.warmup):
+        trainer.step(A, X, L, n_global)
+    barrier()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    g0.record()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(A, X, L, n_global)
+    g1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    if args.traffic_child:
+        return
+    gpu_dt = g0.elapsed_time(g1) * 1e-3                # the same K steps on the GPU's clock: a host stall shows as dt >> gpu_dt
+    h = max(nspin // 2, 1)
+    spin_ms = [round(spin_ev[0].elapsed_time(spin_ev[1]) / h, 4), round(spin_ev[1].elapsed_time(spin_ev[2]) / max(nspin - h, 1), 4)] if nspin >= 2 else None
+    if recs is not None:                                # forward-only timing, every rank (no collective inside), GPU still hot
         nfwd = max(args.steps, 50)
+        for _ in range(10):
+            gcn_gru_forward_raw(A, X, trainer.p_views, model.math, want_stash=False, prepared=trainer._prepared)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(nfwd):
             gcn_gru_forward_raw(A, X, trainer.p_views, model.math, want_stash=False, prepared=trainer._prepared)
         e1.record()
-
-    n_global = world * B                                # fixed global batch: the exchange needs no count collective
-    for _ in range(args.warmup):
-        trainer.step(A, X, L, n_global)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = trainer.step(A, X, L, n_global)
-    barrier()
-    dt = time.perf_counter() - t0
-    if args.traffic_child:
-        return
-    if recs is not None:
-        fwd_s = e0.elapsed_time(e1) * 1e-3 / nfwd       # (both events completed long ago: no wait)
+        torch.cuda.synchronize()
+        fwd_s = e0.elapsed_time(e1) * 1e-3 / nfwd
     trainer.check()                                     # fp16-plane modes: nothing left fp16's range
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -539,6 +569,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "ms_per_step_gpu_clock": round(1e3 * gpu_dt / args.steps, 4),   # same K steps between two events on the stream (diagnostic)
+            "ms_per_step_spinup_halves": spin_ms,                            # the untimed spin-up's two halves (diagnostic: the clock ramp)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -569,7 +601,7 @@ def main():
             "c1_f32_b256": extra.get("c1_f32_b256"),
             "c2_f16_bf16io_b4096": extra.get("c2_f16_bf16io_b4096"),
             "c5_csr_b128": extra.get("c5_csr_b128"),
-            "measurement_order": "traffic children (N=1), untimed per-kernel pass + forward timing, then `warmup` untimed and `steps` timed steps, secondaries (f16x3g_mixed, exact_f32, c1, c2), cpu baseline",
+            "measurement_order": "traffic children (N=1), untimed per-kernel pass + forward output check, %d untimed spin-up steps (clock ramp after the host-synchronising checks), then `warmup` untimed and `steps` timed steps, forward-only timing, secondaries (f16x3g_mixed, exact_f32, c1, c2), cpu baseline" % SPINUP_STEPS,
             "kernels": kernels,
             "kernels_note": "hipEvent-bracketed inside the library: every launch carries 1-2 us of event latency, so the sum "
                             "runs 3-4 % above ms_per_step; the rocprofv3 durations (profiles/*_kernel_stats.csv) sum to it",
