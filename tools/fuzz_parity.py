@@ -77,6 +77,14 @@ for math in args.modes.split(","):
             out, loss, grads = _run_step(model, a_dev, X.to(dev), L.to(dev))
             with torch.no_grad():
                 out2 = model(a_dev, X.to(dev)).cpu()
+            # the same step through TrainStep (wgnn_fwd_loss, deferred backward parts, wgnn_finish with Adam): its loss and the
+            # gradients it leaves in its bucket are those of the parameters BEFORE the update
+            from windgnn_amd.trainer import TrainStep
+            tr = TrainStep(_model_from(p, S, H, math))
+            loss_t, _ = tr.step(a_dev, X.to(dev), L.to(dev))
+            tr.check()
+            grads_t = {key: t.detach().cpu().clone() for key, t in zip(PARAM_KEYS, tr.g_views)}
+            tr.close()
         except Exception as e:                                  # a refused shape is a finding too
             bad.append((tag, "raised %s: %s" % (type(e).__name__, str(e)[:120])))
             continue
@@ -84,6 +92,8 @@ for math in args.modes.split(","):
         worst_y = max(worst_y, ey)
         if ey > y_tol:
             bad.append((tag, "Y %.2e" % ey))
+        if abs(float(loss_t) - float(loss_o)) > (1e-5 if math != "f16" else 2e-2) * max(1.0, float(loss_o)):
+            bad.append((tag, "TrainStep loss %.6f vs %.6f" % (float(loss_t), float(loss_o))))
         if gmax < 1e-8:                                         # saturated: nothing to compare against
             nsat += 1
             continue
@@ -100,6 +110,9 @@ for math in args.modes.split(","):
                 worst_g = max(worst_g, e)
             if e > bar:
                 bad.append((tag, "%s %.2e (bar %.1e; fp32 CPU evaluation: %.1e)" % (key, e, bar, cond[key])))
+            et = rel_to_max(grads_t[key], go[key])
+            if et > bar:
+                bad.append((tag, "TrainStep %s %.2e (bar %.1e; module path %.2e)" % (key, et, bar, e)))
         nbound += int(boundary)
     print("%-7s %d cases (%d CSR; %d with a ReLU pre-activation within fp32 rounding of 0: conv gradients not compared; %d saturated: no gradient compared): "
           "worst |Y - oracle| %.2e (bar %.0e), worst gradient error / max %.2e (bar %.0e; %d tensors of ill-conditioned cases held to 4x the fp32 CPU evaluation's own error instead), %d violations"
