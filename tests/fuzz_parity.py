@@ -3,7 +3,7 @@ for the GPU box): N random shapes per math mode through the drop-in module -- de
 stash-less forward -- against the fp64 oracle at the mode's tolerance.  Prints every violation and a summary.
 H >= 2: with ONE hidden unit every gate of every window hangs on the same three weights rows, the fp32 CPU evaluation itself is
 2e-5 ... 2e-2 off fp64 and the split-fp16 modes another factor 3-5 beyond it (2.8e-4 at S = 16, B = 56: profiles/r5_fuzz_parity.txt).
-    python tools/fuzz_parity.py [--cases 200] [--seed 1] [--modes f32,f16x3,f16x3g,f16]"""
+    python tests/fuzz_parity.py [--cases 200] [--seed 1] [--modes f32,f16x3,f16x3g,f16]"""
 import argparse, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,5 @@
 """Gradient / output errors of the HIP path against the fp64 oracle at S=34, T=24, H=102 (GPU box).
-    [MATH=f16x3] [BS=256,1100] python tools/grad_error_probe.py
+    [MATH=f16x3] [BS=256,1100] python tests/grad_error_probe.py
 Prints, per batch size, max|Y - oracle| and per parameter the error relative to the tensor's max."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -750,7 +750,7 @@ def test_reference_training_loop_body_verbatim_through_the_dropin(fixture, math,
                         # the reference's own trajectory (the spread between the reference's fp32 run and an fp64
                         # evaluation of the same formulas is 3.8e-5 on this fixture: an exact-fp32 kernel with another
                         # summation order cannot be held tighter than that) and all but 0.1 % within 2e-5.
-                        # Observed (tools/tolerance_probe.py, r3): max 2.2e-5 / 2.9e-5 after 1 / 3 steps, ONE element of
+                        # Observed (tests/tolerance_probe.py, r3): max 2.2e-5 / 2.9e-5 after 1 / 3 steps, ONE element of
                         # W_ih beyond 2e-5, every other tensor <= 1.5e-5.
                         assert float(err.max()) <= 4e-5, (it, k, float(err.max()))
                         assert float((err > 2e-5).double().mean()) <= 1e-3, (it, k)
@@ -1091,7 +1091,7 @@ def test_twenty_training_steps_track_the_fp64_oracle(math):
         # of lr = 1e-3 bound the effect at 2e-2, everything else stays within 1e-4 -- and the loss trajectory above,
         # which is what those elements cannot move, agrees at every step
         err = (v.detach().cpu().double() - p[k]).abs()
-        # observed (tools/tolerance_probe.py, r3): f32 max 3.1e-4 with 0.7 % of W_ih beyond 1e-4 and every other tensor
+        # observed (tests/tolerance_probe.py, r3): f32 max 3.1e-4 with 0.7 % of W_ih beyond 1e-4 and every other tensor
         # <= 5.2e-5; f16x3 max 9.8e-4 with 3.5-6.4 % beyond 1e-4.  The bounds below are those observations with a 1.5-2x
         # margin, per mode -- exact fp32 is NOT graded with f16x3's slack.
         frac, worst = float((err > 1e-4).double().mean()), float(err.max())
@@ -1303,7 +1303,7 @@ def test_backward_told_the_loss_statistics_are_in_the_stash_when_they_are_not_is
 def test_f16x3g_is_f16x3_below_4096_rows_and_within_tolerance_above():
     """WGNN_MATH_F16X3G (bench.py's default): below B*T = 4096 rows it is WGNN_MATH_F16X3 bit for bit; from there on the
     forward is still identical (Y bitwise) and the MSE-driven gradients stay inside G_TOL of the fp64 oracle with room to
-    spare (observed at B*T = 6144: 6e-6 of max, f16x3: 1.3e-6; tools/grad_error_probe.py)."""
+    spare (observed at B*T = 6144: 6e-6 of max, f16x3: 1.3e-6; tests/grad_error_probe.py)."""
     from oracle import windgnn_oracle as orc
     dev = _dev()
     S, T, H = 34, 24, 102
