@@ -342,7 +342,7 @@ int wgnn_set_option(int key, int value) {
   if ((key == WGNN_OPT_GG_ROLE_SPLIT && (value < 0 || value > 1)) || (key == WGNN_OPT_GG_GEMM_PRIO && (value < 0 || value > 3)))
     return WGNN_ERR_SHAPE;
   if (key == WGNN_OPT_BIG_GEMM && (value < 0 || value > 1)) return WGNN_ERR_SHAPE;
-  if (key == WGNN_OPT_GEMM32_FORM && (value < 0 || value > 33)) return WGNN_ERR_SHAPE;
+  if (key == WGNN_OPT_GEMM32_FORM && (value < 0 || value > 34)) return WGNN_ERR_SHAPE;
   if (key == WGNN_OPT_BWD2_CHUNKS && value != 1 && value != 2 && value != 4 && value != WGNN_BWD2_MAX_CHUNKS) return WGNN_ERR_SHAPE;
   init_options();
   return g_opt[key].exchange(value, std::memory_order_relaxed);

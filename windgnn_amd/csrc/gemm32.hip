@@ -102,6 +102,9 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
     }
   };
 
+#ifndef G32_EPI_FUSED
+#define G32_EPI_FUSED 1
+#endif
 #ifndef G32_ABLATE          // measurement builds only (tools/exp/gemm32_ablate.sh): 1 no C stores, 2 no DMA after the first
 #define G32_ABLATE 0        // stage, 4 no barrier / wait either (the LDS-read + MFMA loop alone)
 #endif
@@ -112,7 +115,13 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
   // workgroup's epilogue and first stage fall into the other's K loop -- and the chip's C stores do not come as one burst.
   if (stagger > 0 && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
     for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  for (int kt = 0; kt < nk; ++kt) {
+  // The big form finishes its LAST K step column tile by column tile and stores tile j - 1 between the MFMAs of tile j: the
+  // 16 store instructions per column tile issue in the shadow of 64-cycle MFMAs instead of after the loop with the matrix pipe
+  // idle (the epilogue's 16-18 us per product were store ISSUE time: neither a persistent loop nor a second workgroup hid
+  // them, profiles/r5_gemm32_nt_ablation.txt).  Per accumulator the order of its MFMAs is unchanged: bit-identical.
+  constexpr bool FUSE_EPI = MW == 4 && NW == 2 && G32_ABLATE == 0 && G32_EPI_FUSED;
+  const int nloop = FUSE_EPI ? nk - 1 : nk;
+  for (int kt = 0; kt < nloop; ++kt) {
     if (!(G32_ABLATE & 4)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();        // stage kt visible to all waves, stage kt-1 no longer being read
@@ -120,6 +129,35 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
     if (!(G32_ABLATE & 2) && kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kt + 1);
     if (T32 == 1 || tl == T32) compute(smem + (kt & 1) * STAGE, std::integral_constant<int, T32>{});
     else compute(smem + (kt & 1) * STAGE, std::integral_constant<int, (T32 > 1 ? T32 - 1 : 1)>{});
+  }
+  if (FUSE_EPI) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* cur = smem + ((nk - 1) & 1) * STAGE;
+    f32x4 a4[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a4[kk] = *(const f32x4*)(cur + a_row + (((2 * kk + kh) ^ sw) << 4));
+    auto store1 = [&](int j, int r) {
+      const int col = n0 + 32 * T32 * wn + 32 * j + li;
+      const int row = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (col < N && row < M) C[(size_t)row * ldc + col] = acc[j][r];
+    };
+#pragma unroll
+    for (int j = 0; j < T32; ++j) {
+      f32x4 b4[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) b4[kk] = *(const f32x4*)(cur + b_row + j * 32 * 128 + (((2 * kk + kh) ^ sw) << 4));
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          acc[j] = mfma32(a4[kk][jj], b4[kk][jj], acc[j]);
+          if (j > 0) store1(j - 1, 4 * kk + jj);              // one store of the finished tile per MFMA of this one
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) store1(T32 - 1, r);
+    return;
   }
   if (G32_ABLATE & 1) {      // keep the accumulators alive without the stores
     float t = 0.f;
@@ -161,6 +199,133 @@ __global__ void __launch_bounds__(64 * MW * NW) gemm32_nt_kernel(const float* __
         else C[(size_t)row * ldc + col] = acc[j][r];
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT, persistent form of the 4 x 2-wave kernel (one slice of N: nsl = 1).  A workgroup walks its row tiles mt = blockIdx.x,
+// + gridDim.x, ... without leaving the CU: the first stage of the NEXT tile is requested during the last K step of the current
+// one (into the ring slot that step no longer needs), the tile's C stores are issued behind that request, and the next tile's
+// first K step waits with a COUNTED s_waitcnt -- vmcnt counts loads and stores alike and retires them in issue order on
+// gfx9, so "at most as many operations outstanding as stores were issued after the stage's loads" means "the stage has
+// landed" while the stores are still draining under the K step's MFMAs.  (The non-persistent form pays a workgroup turn-around
+// plus a first-stage latency per tile, and its epilogue's drain before s_endpgm: profiles/r5_gemm32_nt_ablation.txt.)
+// Same products in the same order per element as gemm32_nt_kernel<4, 2, T32>: bit-identical results.
+template <int T32>
+__global__ void __launch_bounds__(64 * G_WAVES) gemm32_ntp_kernel(const float* __restrict__ A, int lda, int M, int Kp,
+                                                                const float* __restrict__ Bp, int nb_rows,
+                                                                float* __restrict__ C, int ldc, int N, int nm) {
+  constexpr int G_BM = 128, BN = 64 * T32;
+  constexpr int A_BYTES = G_BM * 128, STAGE = A_BYTES + BN * 128;
+  constexpr int AP = G_BM / 8, BP = BN / 8;                      // 1 KB pieces; AP = 16 = two per wave, then BP / 8 per wave
+  constexpr int NITB = BP / G_WAVES;                             // = T32
+  static_assert(AP == 2 * G_WAVES && BP % G_WAVES == 0, "every wave requests the same number of pieces per stage");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  int mt = blockIdx.x;
+  if (mt >= nm) return;
+
+  const int r8 = lane >> 3, pos = lane & 7;
+  const float* srcB[NITB];
+  int dstB[NITB];
+#pragma unroll
+  for (int it = 0; it < NITB; ++it) {
+    const int blk = wave + G_WAVES * it, row = 8 * blk + r8, chunk = pos ^ ((row >> 1) & 7);
+    srcB[it] = Bp + (size_t)min(row, nb_rows - 1) * Kp + 4 * chunk;
+    dstB[it] = A_BYTES + blk * 1024;
+  }
+  const float* srcA[2];
+  auto set_a = [&](int t) {                                       // the two A pieces of this wave for row tile t
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int blk = wave + G_WAVES * it, row = 8 * blk + r8, chunk = pos ^ ((row >> 1) & 7);
+      srcA[it] = A + (size_t)min(t * G_BM + row, M - 1) * lda + 4 * chunk;      // rows past M: computed, never stored
+    }
+  };
+  auto dma_stage = [&](char* st, int kt) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      __builtin_amdgcn_global_load_lds((glb_void*)(srcA[it] + 32 * kt), (lds_void*)(st + (wave + G_WAVES * it) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < NITB; ++it)
+      __builtin_amdgcn_global_load_lds((glb_void*)(srcB[it] + 32 * kt), (lds_void*)(st + dstB[it]), 16, 0, 0);
+  };
+
+  const int li = lane & 31, kh = lane >> 5, sw = (li >> 1) & 7;
+  const int a_row = (32 * wm + li) * 128, b_row = A_BYTES + (32 * T32 * wn + li) * 128;
+  int livej = 0;                                                  // column tiles of this wave that hold columns of C (uniform)
+#pragma unroll
+  for (int j = 0; j < T32; ++j) livej += (32 * T32 * wn + 32 * j < N) ? 1 : 0;
+  f32x16 acc[T32];
+  const int nk = Kp / 32;
+  int slot = 0;
+  bool first = true;
+  set_a(mt);
+  dma_stage(smem, 0);
+  for (;;) {
+    const int mnext = mt + (int)gridDim.x;
+    const bool has_next = mnext < nm;
+#pragma unroll
+    for (int j = 0; j < T32; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt == 0 && !first) {
+        // issued since this stage's loads: 16 stores per live column tile of the previous row tile (a tile that has a successor is
+        // never the ragged last one: every row < M, every store instruction issued)
+        if (livej >= 4) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else if (livej == 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        else if (livej == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (livej == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();        // this stage visible to all waves, the other slot no longer being read
+      char* cur = smem + slot * STAGE;
+      char* nxt = smem + (slot ^ 1) * STAGE;
+      if (kt + 1 < nk) {
+        dma_stage(nxt, kt + 1);
+      } else if (has_next) {
+        set_a(mnext);
+        dma_stage(nxt, 0);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int co = ((2 * kk + kh) ^ sw) << 4;
+        const f32x4 a = *(const f32x4*)(cur + a_row + co);
+        f32x4 b[T32];
+#pragma unroll
+        for (int j = 0; j < T32; ++j) b[j] = *(const f32x4*)(cur + b_row + j * 32 * 128 + co);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int j = 0; j < T32; ++j) acc[j] = mfma32(a[jj], b[j][jj], acc[j]);
+      }
+      slot ^= 1;
+    }
+    asm volatile("" ::: "memory");          // the stores stay BEHIND the next tile's first-stage loads (the counted wait relies on it)
+    const int m0 = mt * G_BM;
+#pragma unroll
+    for (int j = 0; j < T32; ++j) {
+      if (32 * T32 * wn + 32 * j >= N) continue;                  // uniform: a dead column tile issues nothing
+      const int col = 32 * T32 * wn + 32 * j + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (has_next) {                                           // not the ragged tile: 16 store instructions, no row test
+          if (col < N) C[(size_t)row * ldc + col] = acc[j][r];
+        } else if (col < N && row < M) {
+          C[(size_t)row * ldc + col] = acc[j][r];
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    if (!has_next) break;
+    mt = mnext;
+    first = false;
   }
 }
 
@@ -309,6 +474,24 @@ void nt_shape(int N, bool big, int& nsl, int& T) {
 // 128-row tiles once they give most CUs a workgroup of their own, 32-row tiles below that
 bool nt_big(int M) { return cdiv_i(M, 128) >= 192; }
 
+template <int T32>
+int launch_ntp_t(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, hipStream_t st) {
+  const int nm = cdiv_i(M, 128);
+  const int nb_rows = gemm32_nt_rows(N);
+  const size_t smem = 2 * (size_t)(128 + 64 * T32) * 128;
+  static std::atomic<unsigned long long> done{0};
+  if (ensure_dyn_smem((const void*)gemm32_ntp_kernel<T32>, smem, done) != WGNN_OK) return WGNN_ERR_HIP;
+  static const std::string name = "gemm32_ntp_kernel<128x" + std::to_string(64 * T32) + ">";
+  const double fl = 2.0 * M * (double)N * Kp;
+  const double by = 4.0 * ((double)M * Kp + (double)N * Kp + (double)M * N);
+  const int grid = nm < 256 ? nm : 256;                          // one workgroup per CU, its row tiles 256 apart
+  PROF_LAUNCH(name.c_str(), fl, by, st,
+              hipLaunchKernelGGL((gemm32_ntp_kernel<T32>), dim3(grid), dim3(64 * G_WAVES), smem, st, A, lda, M, Kp, Bp, nb_rows,
+                                 C, ldc, N, nm));
+  WGNN_CHECK_LAUNCH();
+  return WGNN_OK;
+}
+
 template <int MW, int NW, int T32>
 int launch_nt_t(const float* A, int lda, int M, int Kp, const float* Bp, float* C, int ldc, int N, int nsl,
                 hipStream_t st, int stagger = 0) {
@@ -387,7 +570,16 @@ int launch_gemm32_nt(const float* A, int lda, int M, int Kp, const float* Bp, fl
   nt_shape(N, big, nsl, T);
   if (Kp % 32 != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bp & 15)) return WGNN_ERR_SHAPE;
   const int form = opt_gemm32_form();
-  if (big && form > 0) {
+  if (big && form == 34 && nsl == 1) {       // persistent form (one slice of N)
+    switch (T) {
+#define NT_CASE(t) \
+  case t: return launch_ntp_t<t>(A, lda, M, Kp, Bp, C, ldc, N, st);
+      NT_CASE(1) NT_CASE(2) NT_CASE(3) NT_CASE(4) NT_CASE(5) NT_CASE(6) NT_CASE(7)
+#undef NT_CASE
+    }
+    return WGNN_ERR_SHAPE;
+  }
+  if (big && form > 0 && form < 34) {
     // two 4-wave workgroups per CU: 128 x 32 T tiles with T <= 5 (2 x 72 KB of LDS), the N range cut into equal slices of whole
     // 32-column tiles (the last one may hold fewer)
     const int t32 = cdiv_i(N, 32), ns2 = cdiv_i(t32, 5), T2 = cdiv_i(t32, ns2);
