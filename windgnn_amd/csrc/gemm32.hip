@@ -417,8 +417,9 @@ __global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __
   };
 
   const int nk = (kend - kbeg + T_BK - 1) / T_BK;
-  if (nk > 0) dma_stage(smem, kbeg);
-  for (int kt = 0; kt < nk; ++kt) {
+  const int pitch = (No + 15) & ~15;                               // rows of the partials start 64-byte aligned (gemm32_tn_pitch)
+  float* Pz = P + (size_t)z * Mo * pitch;
+  auto enter = [&](int kt) -> char* {
     char* cur = smem + (kt & 1) * STAGE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();        // stage kt landed for all waves, stage kt-1 no longer being read
@@ -428,11 +429,49 @@ __global__ void __launch_bounds__(64 * G_WAVES) gemm32_tn_kernel(const float* __
       __syncthreads();
     }
     if (kt + 1 < nk) dma_stage(smem + ((kt + 1) & 1) * STAGE, kbeg + (kt + 1) * T_BK);
-    compute(cur);
+    return cur;
+  };
+  if (nk > 0) dma_stage(smem, kbeg);
+#ifndef G32TN_EPI_FUSED
+#define G32TN_EPI_FUSED 1
+#endif
+  // The chunk's LAST stage runs column by column of the wave's tile (all eight k groups of a column's five accumulators, then
+  // the next column) and stores column j - 1 -- twenty 4-byte-per-lane store instructions -- between the MFMAs of column j, instead
+  // of 20 T16 stores after the loop with the matrix pipe idle.  Per accumulator the MFMA order is unchanged: bit-identical.
+  const int nloop = (G32TN_EPI_FUSED && nk > 0) ? nk - 1 : nk;
+  for (int kt = 0; kt < nloop; ++kt) compute(enter(kt));
+  if (G32TN_EPI_FUSED && nk > 0) {
+    const char* cur = enter(nk - 1);
+    float a[T_BK / 4][5];
+#pragma unroll
+    for (int kk = 0; kk < T_BK / 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) a[kk][i] = *(const float*)(cur + a_off + (4 * kk * PA + 16 * i) * 4);
+    auto store1 = [&](int i, int j, int r) {
+      const int col = n0 + WN * wn + 16 * j + li;
+      const int row = m0 + 80 * wm + 16 * i + 4 * kq + r;
+      if (col < No && row < Mo) Pz[(size_t)row * pitch + col] = acc[i][j][r];
+    };
+#pragma unroll
+    for (int j = 0; j < T16; ++j) {
+      float b[T_BK / 4];
+#pragma unroll
+      for (int kk = 0; kk < T_BK / 4; ++kk) b[kk] = *(const float*)(cur + b_off + (4 * kk * PB + 16 * j) * 4);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int kk = 0; kk < T_BK / 4; ++kk) {
+          acc[i][j] = mfma16(a[kk][i], b[kk], acc[i][j]);
+          if (j > 0 && (kk & 1)) store1(i, j - 1, kk >> 1);       // 4 stores of tile (i, j - 1) under the 8 MFMAs of tile (i, j)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) store1(i, T16 - 1, r);
+    return;
   }
 
-  const int pitch = (No + 15) & ~15;                               // rows of the partials start 64-byte aligned (gemm32_tn_pitch)
-  float* Pz = P + (size_t)z * Mo * pitch;
 #pragma unroll
   for (int i = 0; i < 5; ++i)
 #pragma unroll
