@@ -178,7 +178,8 @@ const char* wgnn_strerror(int status);
 #define WGNN_OPT_BIG_GEMM 4
 /* Exact-fp32 NT products (GI, dg) from 24 576 rows on: 0 one 8-wave workgroup per CU with a 128 x 64 T tile; v >= 1 two 4-wave
  * workgroups per CU with 128 x 32 T tiles, the second of each pair started (v - 1) x 3.4 us late so that one's epilogue falls
- * into the other's K loop (v <= 33).  Same products, same summation order per element: results are bit-identical. */
+ * into the other's K loop (v <= 33); 34 the persistent form of the
+ * 8-wave kernel (cross-tile prefetch, counted waits).  Same products, same summation order per element: results are bit-identical. */
 #define WGNN_OPT_GEMM32_FORM 5
 #define WGNN_OPT_COUNT 6
 int wgnn_set_option(int key, int value);

@@ -1638,7 +1638,9 @@ def test_exact_fp32_projection_as_two_workgroups_per_cu_is_bitwise_the_one_workg
     """WGNN_OPT_GEMM32_FORM (a schedule option, round 5): the exact-fp32 NT products (GI, dg) from 24 448 rows on as two 4-wave
     workgroups per CU (128 x 160 tiles; dg's 14 column tiles as slices of 5, 5 and 4) with and without the late start, against
     the one 8-wave workgroup form: every element is the same fp32 chain, so Y, the loss and all eight gradients are bit-identical;
-    1100 windows x 24 = 26 400 rows leave a ragged last row tile (26 400 = 206 x 128 + 32)."""
+    1100 windows x 24 = 26 400 rows leave a ragged last row tile (26 400 = 206 x 128 + 32).  Form 34 is the persistent kernel
+    (cross-tile prefetch, counted waits, stores after the loop); form 0 issues its stores inside the last K step: three
+    different epilogues, one result."""
     from oracle import windgnn_oracle as orc
     from windgnn_amd import _lib
     dev = _dev()
@@ -1651,12 +1653,12 @@ def test_exact_fp32_projection_as_two_workgroups_per_cu_is_bitwise_the_one_workg
     L = torch.rand(B, T, H, generator=g)
     res = {}
     try:
-        for form in (0, 1, 6):
+        for form in (0, 1, 6, 34):
             _lib.set_option(_lib.OPT_GEMM32_FORM, form)
             res[form] = _run_step(_model_from(p, S, H, "f32"), A.to(dev), X.to(dev), L.to(dev))
     finally:
         _lib.set_option(_lib.OPT_GEMM32_FORM, 0)
-    for form in (1, 6):
+    for form in (1, 6, 34):
         assert torch.equal(res[0][0], res[form][0]) and res[0][1] == res[form][1]
         for k in PARAM_KEYS:
             assert torch.equal(res[0][2][k], res[form][2][k]), (form, k)
